@@ -1,0 +1,288 @@
+"""
+ORACLE -- test infrastructure, NOT the product.
+
+CPU (numpy) restatement of the batched ray-propagation hot path of
+python-msgwam (`lib/libprop.py` + the step wrapper of `raytracer.py`).  Only
+`tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py`
+may import this module; the product path (`python-msgwam_amd/`) never does
+and fails loudly when its HIP extension is missing.
+
+Parity is PINNED: every function below is checked in `tests/test_oracle_golden.py`
+against fixtures in `tests/golden/*.npz` that `oracle/gen_golden.py` produced by
+importing the real reference (`/root/reference/lib/libprop.py`) in the build
+container (numpy 2.2.6).  Citations are `file:line` relative to the reference
+root.
+
+Design: the oracle keeps NO module-global state (the reference does,
+`lib/libprop.py:3-11`); everything lives in a `Setup` object.  Arithmetic is
+written operation by operation in the reference's order so that results are
+bit-comparable with numpy's evaluation of the reference expressions.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+RAD_EARTH = 6378e3      # lib/libprop.py:3
+ROT_EARTH = 7.2921e-5   # lib/libprop.py:4
+
+# Williamson low-storage RK3 coefficients exactly as the reference writes them
+# (python float expressions, lib/libprop.py:693-698)
+RK_A = (0.0, 5 / 9, 153 / 128)          # q = dt*f - A*q
+RK_B15_16 = 15 / 16
+RK_B8_15 = 8 / 15
+
+
+class Setup:
+    """Everything the reference keeps in module globals (lib/libprop.py:3-11,
+    :14-44): config scalars, the column grids and the per-ray statics."""
+
+    def __init__(self, grid, bvf=0.01, phi0=0.0, kappa=1.0, saturate_online=False,
+                 hh=8500.0, rhobar0=1.2, boussinesq=False, dkk=None, dll=None,
+                 rr_mm_area=None):
+        self.grid = np.asarray(grid, dtype=np.float64)
+        self.grids = .5 * (self.grid[:-1] + self.grid[1:])       # raytracer.py:75
+        self.bvf = bvf
+        self.phi0 = phi0
+        self.kappa = kappa
+        self.saturate_online = saturate_online
+        self.hh = hh
+        self.rhobar0 = rhobar0
+        self.boussinesq = boussinesq
+        self.dkk = dkk
+        self.dll = dll
+        self.rr_mm_area = rr_mm_area
+        # lib/libprop.py:47-62 set_hydrostatics
+        if boussinesq:
+            self.rhobar = rhobar0 * np.ones(self.grids.shape)
+        else:
+            self.rhobar = rhobar0 * np.exp(-self.grids / hh)
+        self.pressure_gradient = np.zeros((2, len(self.grids)))
+
+    def set_pressure_gradient(self, uu, vv):
+        """lib/libprop.py:65-82"""
+        ff = 2 * ROT_EARTH * np.sin(self.phi0)
+        pg = np.empty((2, len(self.grids)))
+        pg[0] = self.rhobar * ff * vv
+        pg[1] = - self.rhobar * ff * uu
+        self.pressure_gradient = pg
+
+
+def velocities_sine_homogeneous(rr, u0, rr0, sig_rr):
+    """lib/libprop.py:306-325 (host-side setup of the column only)."""
+    exponential = .5 * (np.tanh((rr - rr0) / sig_rr) + 1)
+    return u0 * exponential * np.sin(rr / sig_rr * 2 * np.pi)
+
+
+# --------------------------------------------------------------------------
+# a-4  dispersion relation and vertical group velocity
+# --------------------------------------------------------------------------
+def omega(kk, ll, mm, phi, bvf):
+    """lib/libprop.py:369-383"""
+    ff = 2 * ROT_EARTH * np.sin(phi)
+    return np.sqrt((bvf ** 2 * (kk ** 2 + ll ** 2) + ff ** 2 * mm ** 2)
+                   / (kk ** 2 + ll ** 2 + mm ** 2))
+
+
+def cg_rr(kk, ll, mm, phi, bvf):
+    """lib/libprop.py:434-448 (lam, rr are unused there)."""
+    vk_square = kk ** 2 + ll ** 2 + mm ** 2
+    ff = 2 * ROT_EARTH * np.sin(phi)
+    om = omega(kk, ll, mm, phi, bvf)
+    return - mm * (om ** 2 - ff ** 2) / om / vk_square
+
+
+# --------------------------------------------------------------------------
+# a-5  shear interpolation
+# --------------------------------------------------------------------------
+def shear_at_rays(setup, rr, uu, vv):
+    """lib/libprop.py:349-356: first differences on the interior interfaces and
+    np.interp (piecewise linear, end-value clamping) to the ray heights."""
+    grid = setup.grid
+    dz = np.diff(grid[:2])[0]
+    du_dz = (uu[1:] - uu[:-1]) / dz
+    dv_dz = (vv[1:] - vv[:-1]) / dz
+    return (np.interp(rr, grid[1:-1], du_dz), np.interp(rr, grid[1:-1], dv_dz))
+
+
+# --------------------------------------------------------------------------
+# a-3  wave_projection  (var = 0, 1, 2)
+# --------------------------------------------------------------------------
+def _projection_indices(rr_low, rr_up, G):
+    """lib/libprop.py:123-135.  Returns dz, nlow, nup (clipped), skip mask."""
+    dz = np.diff(G[:2])[0]
+    with np.errstate(invalid='ignore', over='ignore'):
+        nlow = (rr_low / dz).astype(int)            # trunc toward zero
+        nup = (rr_up / dz + 1.).astype(int)
+    nzmax = len(G) - 2
+    ood = (((nlow >= nzmax) & (nup >= nzmax)) | ((nlow <= 0) & (nup <= 0)))
+    nlow = np.clip(nlow, 0, nzmax)                  # :133-134 (on raw indices)
+    nup = np.clip(nup, 0, nzmax)
+    return dz, nlow, nup, ood
+
+
+def wave_projection(dens, rr_low, rr_up, kk, ll, mm_low, mm_up, phi,
+                    dkk, dll, dmm, G, bvf, var=0, loop=False):
+    """lib/libprop.py:92-197 for var in {0, 1, 2}.
+
+    `loop=False` is a vectorised closed form that accumulates in exactly the
+    reference's order (ray-major, then cell), so it is bit-identical to
+    `loop=True`, which keeps the reference's interpreted double loop
+    (:151-163) and is what `bench.py` times as the 1-core CPU baseline.
+    """
+    G = np.asarray(G, dtype=np.float64)
+    dz, nlow, nup, ood = _projection_indices(rr_low, rr_up, G)
+    phase_space_vol = abs(dkk * dll * dmm)                       # :137
+    cgr = cg_rr(kk, ll, .5 * (mm_low + mm_up), phi, bvf)         # :139-144
+    if var == 0:
+        payload = (cgr * kk * dens, cgr * ll * dens)             # :148-149
+    elif var == 1:
+        payload = (cgr * dens,)                                  # :167
+    elif var == 2:
+        payload = (dens,)                                        # :184
+    else:
+        raise ValueError("oracle covers var 0, 1, 2 (3/4 have no caller)")
+    ncell = len(G) - 1
+    out = np.zeros((len(payload), ncell))
+
+    if loop:
+        for nr in range(len(dens)):
+            if ood[nr]:
+                continue
+            for ncell_ in range(nlow[nr], nup[nr]):
+                zmin = np.max([G[ncell_], rr_low[nr]])
+                zmax = np.min([G[ncell_ + 1], rr_up[nr]])
+                dri_o_dr = np.abs(zmax - zmin) / dz
+                for p, v in enumerate(payload):
+                    out[p, ncell_] += dri_o_dr * phase_space_vol[nr] * v[nr]
+    else:
+        cnt = np.where(ood, 0, np.maximum(nup - nlow, 0))
+        total = int(cnt.sum())
+        if total:
+            ray = np.repeat(np.arange(len(dens)), cnt)
+            first = np.cumsum(cnt) - cnt
+            cell = nlow[ray] + (np.arange(total) - first[ray])
+            zmin = np.maximum(G[cell], rr_low[ray])
+            zmax = np.minimum(G[cell + 1], rr_up[ray])
+            w = np.abs(zmax - zmin) / dz
+            for p, v in enumerate(payload):
+                # bincount adds sequentially in array order == ray order
+                out[p] = np.bincount(cell, weights=w * phase_space_vol[ray] * v[ray],
+                                     minlength=ncell)
+    return out if var == 0 else out[0]
+
+
+# --------------------------------------------------------------------------
+# a-7  saturation
+# --------------------------------------------------------------------------
+def saturation(setup, dt, dens, rr_center, rr_center_st, drr, drr_st, kk, ll,
+               mm_center, mm_center_st, direct=False):
+    """lib/libprop.py:561-615"""
+    phi0, NN, kappa = setup.phi0, setup.bvf, setup.kappa
+    ff = 2 * ROT_EARTH * np.sin(phi0)
+    rr_final = rr_center + rr_center_st * dt
+    drr_final = drr + drr_st * dt
+    mm_final = mm_center + mm_center_st * dt
+    dmm_final = setup.rr_mm_area / drr_final
+    rhobar_final = np.interp(rr_final, setup.grids, setup.rhobar)
+    omh = omega(kk, ll, mm_center, phi0, NN)
+    phase_volume = setup.dkk * setup.dll * dmm_final
+    with np.errstate(divide='ignore', invalid='ignore'):
+        max_dens_final = (kappa ** 2 * .5 * rhobar_final * omh * NN ** 2
+                          / mm_final ** 2 / (omh ** 2 - ff ** 2))
+    hit = max_dens_final < dens * phase_volume
+    if direct:
+        dens_new = dens.copy()
+        dens_new[hit] = max_dens_final[hit]
+        return dens_new
+    dens_st = np.zeros(dens.shape)
+    dens_st[hit] = (max_dens_final[hit] - dens[hit]) / dt
+    return dens_st
+
+
+# --------------------------------------------------------------------------
+# a-2 / a-6  right-hand side  (HPROP_GLOBAL = False branch, scalar bvf)
+# --------------------------------------------------------------------------
+def rhs(setup, dt, state, loop=False, fixed_background=False, return_flux=False):
+    """lib/libprop.py:618-676 with HPROP_GLOBAL=False (raytracer.py:38).
+
+    state = [dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv].
+    `fixed_background=True` is the rhs-hook variant of BASELINE config 1/2:
+    identical tendencies with slots 9, 10 zeroed.
+    """
+    dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = state
+    bvf = setup.bvf
+    cgr_up = cg_rr(kk, ll, mm, phi, bvf)                 # :635 (rr unused)
+    cgr_down = cg_rr(kk, ll, mm, phi, bvf)               # :636
+    zeros = np.zeros(np.shape(kk))
+    # :638-639  cg_lambda/cg_phi return zeros when HPROP is off
+    dlam_st = zeros / (RAD_EARTH + rr) / np.cos(phi)
+    dphi_st = zeros / (RAD_EARTH + rr)
+    drr_st = .5 * (cgr_down + cgr_up)                    # :640
+    ddrr_st = cgr_up - cgr_down                          # :641
+    dkk_st = np.zeros(np.shape(kk))                      # :470-471
+    dll_st = np.zeros(np.shape(kk))                      # :498-499
+    du_dz_ray, dv_dz_ray = shear_at_rays(setup, rr, uu, vv)
+    gradient = (kk * du_dz_ray + ll * dv_dz_ray)         # :517
+    dmm_st = (kk * zeros + ll * zeros) / (RAD_EARTH + rr) - gradient   # :519-520
+    ddmm_st = dmm / drr * ddrr_st                        # :645
+    dens_st = setup.saturate_online * saturation(        # :647-651
+        setup, dt, dens, rr, drr_st, drr, ddrr_st, kk, ll, mm, dmm_st)
+
+    grid, grids = setup.grid, setup.grids
+    pm_flux = np.zeros((2, len(grid)))                   # :653
+    pm_flux[:, 1:-1] = wave_projection(                  # :654-658
+        dens, rr - .5 * drr, rr + .5 * drr, kk, ll, mm - .5 * dmm, mm + .5 * dmm,
+        phi, setup.dkk, setup.dll, dmm, grids, bvf, var=0, loop=loop)
+    pm_flux[:, 0] = pm_flux[:, 1]
+    pm_flux[:, -1] = pm_flux[:, -2]
+    dz = np.diff(grid[:2])[0]
+    pm_flux_gradient = (pm_flux[:, 1:] - pm_flux[:, :-1]) / dz     # :663
+
+    ff0 = 2 * ROT_EARTH * np.sin(setup.phi0)
+    pg = setup.pressure_gradient
+    du_st = ff0 * vv - setup.rhobar ** -1 * (pg[0] + pm_flux_gradient[0])   # :537
+    dv_st = -ff0 * uu - setup.rhobar ** -1 * (pg[1] + pm_flux_gradient[1])  # :556
+    if fixed_background:
+        du_st = np.zeros_like(du_st)
+        dv_st = np.zeros_like(dv_st)
+    out = [dens_st, dlam_st, dphi_st, drr_st, ddrr_st, dkk_st, dll_st,
+           dmm_st, ddmm_st, du_st, dv_st]
+    if return_flux:
+        return out, pm_flux
+    return out
+
+
+def rk3(setup, dt, state, loop=False, fixed_background=False):
+    """lib/libprop.py:680-700, slot by slot (so nray == ngrid-1 cannot collapse
+    the object array as it does in the reference)."""
+    var = [np.asarray(s, dtype=np.float64) for s in state]
+    f = lambda v: rhs(setup, dt, v, loop=loop, fixed_background=fixed_background)
+    qq = [dt * r for r in f(var)]
+    var = [v + q / 3 for v, q in zip(var, qq)]
+    qq = [dt * r - 5 / 9 * q for r, q in zip(f(var), qq)]
+    var = [v + 15 / 16 * q for v, q in zip(var, qq)]
+    qq = [dt * r - 153 / 128 * q for r, q in zip(f(var), qq)]
+    var = [v + 8 / 15 * q for v, q in zip(var, qq)]
+    return var
+
+
+# --------------------------------------------------------------------------
+# a-8  the driver's step wrapper
+# --------------------------------------------------------------------------
+def driver_step(setup, dt, state, loop=False, fixed_background=False,
+                ref_quirks=True):
+    """raytracer.py:157-188: RK3, then (if not saturate_online) the direct
+    saturation with the driver's argument quirks: rr tendency divided by 1
+    instead of dt (:184), new kk/ll, old mm (:186).
+    Returns (state_out with saturated dens, dens_prop)."""
+    old = [np.asarray(s, dtype=np.float64) for s in state]
+    new = rk3(setup, dt, old, loop=loop, fixed_background=fixed_background)
+    dens_prop = new[0]
+    if not setup.saturate_online:
+        rr_div = 1 if ref_quirks else dt
+        new = list(new)
+        new[0] = saturation(
+            setup, dt, dens_prop, old[3], (new[3] - old[3]) / rr_div,
+            old[4], (new[4] - old[4]) / dt, new[5], new[6], old[7],
+            (new[7] - old[7]) / dt, direct=True)
+    return new, dens_prop
