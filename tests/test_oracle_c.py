@@ -1,0 +1,102 @@
+"""The plain-C restatement (oracle/msgwam_oracle.c) against the golden vectors
+from the real reference and against the numpy oracle.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import msgwam_oracle as orc
+from oracle.c_oracle import COracle
+from helpers import STATE_KEYS, load, setup_from, state_from, relerr
+
+FAST = ("dens", "rr", "mm", "uu", "vv")
+
+
+@pytest.mark.parametrize("name", ["g1_rhs_f0_sat0", "g1_rhs_f0_sat1", "g1_rhs_f45_sat0", "g1_rhs_f45_sat1"])
+def test_c_rhs_bit_exact(name):
+    d = load(name)
+    co = COracle(setup_from(d))
+    out = co.rhs(float(d["dt"]), state_from(d, "in"))
+    for k in FAST:
+        np.testing.assert_array_equal(out[k], d[f"out_{k}"], err_msg=k)
+    np.testing.assert_array_equal(out["pm_flux"][:, 1:-1], d["pm_flux_inner"])
+
+
+@pytest.mark.parametrize("var", [0, 1, 2])
+def test_c_projection(var):
+    d = load("g2_projection")
+    g101 = d["grid101"]
+    s = orc.Setup(g101, dkk=d["rand_dkk"], dll=d["rand_dll"], rr_mm_area=d["rand_area"])
+    co = COracle(s)
+    st = [d["rand_" + k] for k in STATE_KEYS[:9]]
+    for gname, G in (("grid", g101), ("grids", s.grids)):
+        np.testing.assert_array_equal(co.project(st, G, var), d[f"rand_{gname}_var{var}"])
+    # edge table, one ray at a time
+    e = d["edges"]
+    one = np.ones(1)
+    s1 = orc.Setup(d["grid11"], dkk=one, dll=one, rr_mm_area=one)
+    c1 = COracle(s1)
+    for gname, G in (("G10", d["G10"]), ("grid", d["grid11"]), ("grids", d["grids11"])):
+        for i in range(len(e)):
+            st = [one, 0 * one, 0 * one, np.array([.5 * (e[i, 0] + e[i, 1])]), np.array([e[i, 1] - e[i, 0]]),
+                  2e-4 * one, 1e-4 * one, -1e-3 * one, one]
+            lo, up = st[3] - .5 * st[4], st[3] + .5 * st[4]
+            if lo[0] != e[i, 0] or up[0] != e[i, 1]:
+                continue        # centre/width form does not reproduce these edges exactly
+            # the fixture passed mm_low = mm_up = -1e-3 with dmm = 1; through (mm, dmm) the
+            # mid-point wavenumber is rounded differently, so cgr payloads get 1e-12, weights exact
+            got, want = c1.project(st, G, var), d[f"edgerows_{gname}_var{var}"][i]
+            if var == 2:
+                np.testing.assert_array_equal(got, want, err_msg=f"{gname} ray {i}")
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-12, atol=0, err_msg=f"{gname} ray {i}")
+
+
+@pytest.mark.parametrize("name,marks,fixed", [
+    ("g3_rk3_coupled_driver", (1, 10, 100), False),
+    ("g3_rk3_coupled_f45", (1, 10, 100), False),
+    ("g3_rk3_fixedbg_config1", (1, 10, 100, 1000), True),
+    ("g4_saturation_online", (1, 5, 20, 60), False),
+    ("g5_spectrum_coupled", (1, 3), False),
+])
+def test_c_rk3(name, marks, fixed):
+    d = load(name)
+    co = COracle(setup_from(d), fixed_background=fixed)
+    st = state_from(d, "in")
+    done = 0
+    for n in marks:
+        st = co.step(float(d["dt"]), n - done, st)
+        done = n
+        for k, a in zip(STATE_KEYS, st):
+            assert relerr(a, d[f"s{n}_{k}"]) <= 1e-12, (n, k)
+
+
+def test_c_driver_direct_saturation():
+    d = load("g4_saturation_direct_driver")
+    co = COracle(setup_from(d))
+    st = state_from(d, "in")
+    done = 0
+    for n in (1, 10, 100, 709, 710, 711, 1000, 1440):
+        st = co.step(float(d["dt"]), n - done, st, direct_sat=1)
+        done = n
+        tol = 1e-10 if n <= 1000 else 1e-7
+        for k, a in zip(STATE_KEYS, st):
+            assert relerr(a, d[f"s{n}_{k}"]) <= tol, (n, k)
+
+
+def test_c_matches_numpy_oracle_random():
+    rng = np.random.default_rng(7)
+    n = 3000
+    grid = np.linspace(0, 100e3, 101)
+    s = orc.Setup(grid, phi0=0.4, kappa=0.95, saturate_online=True,
+                  dkk=np.full(n, 1e-4), dll=np.full(n, 1e-4), rr_mm_area=rng.uniform(1e-3, 1e-1, n))
+    uu = orc.velocities_sine_homogeneous(s.grids, 4.0, 40e3, 10e3)
+    vv = 0.3 * uu[::-1]
+    s.set_pressure_gradient(uu, vv)
+    rr = rng.uniform(-1e3, 105e3, n)
+    drr = rng.uniform(50, 4000, n)
+    kk, ll = rng.normal(0, 1e-4, n), rng.normal(0, 1e-4, n)
+    mm = rng.normal(0, 2e-3, n)
+    st = [rng.uniform(0, 1e9, n), np.zeros(n), np.full(n, 0.4), rr, drr, kk, ll, mm, s.rr_mm_area / drr, uu, vv]
+    a = orc.rk3(s, 60.0, st)
+    b = COracle(s).step(60.0, 1, st)
+    for k, x, y in zip(STATE_KEYS, a, b):
+        np.testing.assert_array_equal(x, y, err_msg=k)
