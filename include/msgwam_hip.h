@@ -1,0 +1,166 @@
+/*
+ * msgwam_hip.h -- C ABI of the MI355X (gfx950) ray-propagation library.
+ *
+ * The reference (dsconnelly/python-msgwam) has NO FFI: its boundary for this
+ * path is the Python module surface of lib/libprop.py as used by raytracer.py.
+ * Each entry point below names the reference interface it stands behind
+ * (file:line relative to the reference root).  The Python mirror of that
+ * module surface lives in python-msgwam_amd/msgwam_amd/libprop.py and reaches
+ * these functions through ctypes.
+ *
+ * Conventions: plain pointers + sizes; every host pointer is caller-owned and
+ * only read/written during the call; device memory is owned by the opaque
+ * context.  Return value 0 = ok, < 0 = error (text via msgw_last_error).
+ * No C++ exceptions cross this boundary.  One context per GPU; a context is
+ * not thread-safe.  NaN/inf propagate as in numpy, nothing traps.
+ *
+ * All floating-point data is float64 (the reference is float64 throughout).
+ * Scope: the HPROP_GLOBAL = False branch with scalar bvf, i.e. the driver's
+ * configuration (raytracer.py:38); there only dens, rr, mm and the uu, vv
+ * columns evolve, so only those are ever copied back.
+ */
+#ifndef MSGWAM_HIP_H
+#define MSGWAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msgw_ctx msgw_ctx;
+
+#define MSGW_ABI_VERSION 1
+
+/* error codes */
+#define MSGW_OK            0
+#define MSGW_ERR_ARG      -1   /* bad argument / call order                 */
+#define MSGW_ERR_HIP      -2   /* a HIP runtime call failed                  */
+#define MSGW_ERR_NOGPU    -3   /* no usable gfx950 device                    */
+#define MSGW_ERR_RCCL     -4   /* RCCL missing or a collective failed        */
+#define MSGW_ERR_UNSUP    -5   /* outside the supported scope (e.g. HPROP)   */
+
+/* flags of msgw_step / msgw_rhs */
+#define MSGW_FIXED_BACKGROUND   1u  /* rhs hook that zeroes slots 9,10: no deposit, column frozen */
+#define MSGW_DIRECT_SAT_QUIRK   2u  /* driver's post-step saturation, rr tendency "/ 1" (raytracer.py:184) */
+#define MSGW_DIRECT_SAT         4u  /* the same with "/ dt"                                         */
+#define MSGW_NO_GRAPH           8u  /* launch kernels eagerly instead of replaying a hipGraph       */
+#define MSGW_TIME_KERNELS      16u  /* bracket every ray-stage kernel with HIP events (implies NO_GRAPH) */
+
+/* counters filled by msgw_counters */
+typedef struct {
+    double  last_step_ms;        /* HIP-event time of the last msgw_step call (whole call)       */
+    double  ray_kernel_ms_sum;   /* sum of ray-stage kernel durations (MSGW_TIME_KERNELS only)   */
+    int64_t ray_kernel_launches; /* number of ray-stage launches behind that sum                 */
+    int64_t ray_steps_total;     /* rays x RK3 steps advanced since create                       */
+    int64_t nray;                /* rays resident                                               */
+    int32_t ngrid;               /* interfaces                                                  */
+    int32_t blocks;              /* workgroups of the ray-stage kernel                          */
+    int32_t graph_steps;         /* RK3 steps per captured graph (0 = eager)                    */
+    int32_t nranks;              /* communicator size (1 = no collective)                       */
+} msgw_counters_t;
+
+/* ABI version of the loaded library (== MSGW_ABI_VERSION). */
+int msgw_abi_version(void);
+
+/* Last error text; ctx may be NULL for errors of msgw_create itself. */
+const char *msgw_last_error(const msgw_ctx *ctx);
+
+/* Create a context on HIP device `device` for at most nray_cap rays on a
+ * column with ngrid interfaces (len(lprop.grid), raytracer.py:74-77). */
+int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid);
+int msgw_destroy(msgw_ctx *ctx);
+
+/* model_config scalars read by the hot path (lib/libprop.py:380, :534, :582-584,
+ * :633) and the module flag HPROP_GLOBAL (lib/libprop.py:5, raytracer.py:38).
+ * f0 = 2*ROT_EARTH*sin(phi0) is computed by the caller in numpy so that sin()
+ * is bit-identical to the reference.  hprop != 0 -> MSGW_ERR_UNSUP. */
+int msgw_set_config(msgw_ctx *ctx, double bvf, double f0, double kappa,
+                    int saturate_online, int hprop);
+
+/* The column: lprop.grid [ngrid], lprop.grids [ngrid-1] (raytracer.py:76-77),
+ * lprop.rhobar [ngrid-1] (set_hydrostatics, lib/libprop.py:47-62),
+ * lprop.pressure_gradient [2][ngrid-1] (lib/libprop.py:65-82), and the wind
+ * columns uu, vv [ngrid-1] = state slots 9, 10 (lib/libprop.py:629). */
+int msgw_set_column(msgw_ctx *ctx, const double *grid, const double *grids,
+                    const double *rhobar, const double *pgrad,
+                    const double *uu, const double *vv);
+
+/* Per-ray state slots 0,3,4,5,6,7,8 of the RK3 state vector (lib/libprop.py:629;
+ * raytracer.py:160-172) plus the per-ray statics dkk, dll, rr_mm_area
+ * (set_statics, lib/libprop.py:14-27; raytracer.py:105-109) and
+ * fray[i] = 2*ROT_EARTH*sin(phi[i]) (slot 2, computed in numpy).  Slots 1, 2
+ * (lam, phi) never change with HPROP off and stay on the host. */
+int msgw_upload_rays(msgw_ctx *ctx, int64_t n,
+                     const double *dens, const double *rr, const double *drr,
+                     const double *kk, const double *ll, const double *mm,
+                     const double *dmm, const double *fray,
+                     const double *dkk, const double *dll, const double *rr_mm_area);
+
+/* lprop.RK3(dt, state) applied nsteps times (lib/libprop.py:680-700 calling
+ * rhs_default :618-676 three times per step), state resident on the device.
+ * With MSGW_DIRECT_SAT* each step is followed by the driver's
+ * lprop.saturation(..., direct=True) (raytracer.py:182-188). */
+int msgw_step(msgw_ctx *ctx, double dt, int nsteps, unsigned flags);
+
+/* One evaluation of rhs_default (lib/libprop.py:618-676) on the resident state:
+ * tendencies of slots 0 (dens), 3 (rr), 7 (mm) [n each], 9, 10 (uu, vv)
+ * [ngrid-1 each] and pm_flux [2][ngrid] (lib/libprop.py:653-660).  Any output
+ * pointer may be NULL.  Tendencies of the other slots are identically zero. */
+int msgw_rhs(msgw_ctx *ctx, double dt, unsigned flags,
+             double *st_dens, double *st_rr, double *st_mm,
+             double *st_uu, double *st_vv, double *pm_flux);
+
+/* lprop.wave_projection(..., grid, var) (lib/libprop.py:92-197) of the resident
+ * rays for var in {0,1,2} on an arbitrary uniform grid G [nG]; out is
+ * [2][nG-1] for var 0 and [nG-1] otherwise (raytracer.py:213, :227). */
+int msgw_project(msgw_ctx *ctx, int var, const double *G, int nG, double *out);
+
+/* lprop.wave_projection(dens, lam, phi, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk,
+ * dll, dmm, grid, var) (lib/libprop.py:92-197) on caller-supplied host arrays
+ * [n each]; fray[i] = 2*ROT_EARTH*sin(phi[i]); lam is unused by the reference.
+ * Independent of the resident state (only the stream and scratch are used). */
+int msgw_project_arrays(msgw_ctx *ctx, int64_t n, int var, double bvf,
+                        const double *dens, const double *rr_low, const double *rr_up,
+                        const double *kk, const double *ll, const double *mm_low,
+                        const double *mm_up, const double *dkk, const double *dll,
+                        const double *dmm, const double *fray,
+                        const double *G, int nG, double *out);
+
+/* lprop.saturation(dt, dens, rr_center, rr_center_st, drr, drr_st, kk, ll,
+ * mm_center, mm_center_st, direct) (lib/libprop.py:561-615) on caller arrays,
+ * with statics dkk, dll, rr_mm_area (:585-587) passed explicitly; uses the
+ * resident config (bvf, f0, kappa) and column (grids, rhobar).  out [n]:
+ * the saturated density (direct != 0, :606-610) or its tendency (:612-615). */
+int msgw_saturation(msgw_ctx *ctx, int64_t n, double dt, int direct,
+                    const double *dens, const double *rr_center, const double *rr_center_st,
+                    const double *drr, const double *drr_st, const double *kk, const double *ll,
+                    const double *mm_center, const double *mm_center_st,
+                    const double *dkk, const double *dll, const double *rr_mm_area,
+                    double *out);
+
+/* Copy the evolving slots back (blocking). Any pointer may be NULL. */
+int msgw_download_rays(msgw_ctx *ctx, int64_t n, double *dens, double *rr, double *mm);
+int msgw_download_column(msgw_ctx *ctx, double *uu, double *vv);
+
+/* Wait for all queued work of this context. */
+int msgw_sync(msgw_ctx *ctx);
+
+/* Multi-GPU (no reference counterpart: the reference is single-process).
+ * Rays are sharded across ranks; the per-stage flux profile (2 x (ngrid-2)
+ * float64) is all-reduced with RCCL before the mean-flow update.
+ * msgw_comm_unique_id fills a 128-byte ncclUniqueId on rank 0; every rank then
+ * calls msgw_comm_init with the same id. */
+int msgw_comm_unique_id(void *id128);
+int msgw_comm_init(msgw_ctx *ctx, const void *id128, int rank, int nranks);
+
+/* Tuning knobs: workgroups per CU of the ray-stage kernel (default 4) and RK3
+ * steps per captured hipGraph (default 4; 0 = always eager). */
+int msgw_set_tuning(msgw_ctx *ctx, int blocks_per_cu, int graph_steps);
+
+int msgw_counters(msgw_ctx *ctx, msgw_counters_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSGWAM_HIP_H */

@@ -1,0 +1,154 @@
+// K2: flux finalise + mean-flow update, one workgroup (the column has
+// O(100..1000) levels).  Deterministic: per-workgroup flux rows are summed in
+// a fixed (segment, workgroup) order, independent of scheduling.
+#pragma once
+#include "ray_kernels.h"
+
+namespace msgw {
+
+struct ColArgs {
+    int ng;               // interfaces
+    int nblocks;          // rows in `partial`
+    int nseg;             // row segments summed in parallel
+    int npay;             // payload rows per workgroup row (2 for the RHS, 1 or 2 for diagnostics)
+    int ncp;              // levels per payload row
+    int fixed_background;
+    double dt, f0, dzg;   // f0 = 2*Omega*sin(phi0) (:535); dzg = grid[1]-grid[0] (:349, :662)
+    const double *partial;
+    const int *ranges;
+    double *flux;         // [npay][ncp] reduced (this rank's) flux profile
+    const double *rhobar, *pg;
+    double *uu, *vv, *q_uu, *q_vv;
+    const double *xg;
+    double *dudz, *dvdz, *slu, *slv;
+    double *out_du, *out_dv, *out_flux;   // probe outputs (device)
+};
+
+constexpr int COL_REDUCE = 1;   // sum the workgroup rows into `flux`
+constexpr int COL_UPDATE = 2;   // mean-flow tendencies / RK update / shear columns from `flux`
+
+// STAGE 0,1,2: RK stage of slots 9, 10 (lib/libprop.py:693-698 applied to uu, vv)
+// STAGE 3    : probe -- du_dt, dv_dt and pm_flux written out, nothing updated
+// STAGE 4    : derive dudz/dvdz/slopes from the current uu, vv only
+template <int STAGE, int MODE>
+__global__ void __launch_bounds__(COL_BLOCK) k_column(const ColArgs a)
+{
+    extern __shared__ double lds[];
+    const int ng = a.ng, nc = ng - 1, ni = ng - 2;
+    const int ncols = a.npay * a.ncp;
+    double *s_F = lds;                      // [2][ng]
+    double *s_u = s_F + 2 * ng;             // [nc]
+    double *s_v = s_u + nc;                 // [nc]
+    double *s_du = s_v + nc;                // [ni]
+    double *s_dv = s_du + ni;               // [ni]
+    double *s_seg = s_dv + ni;              // [nseg][ncols]
+    int *s_rng = reinterpret_cast<int *>(s_seg + (size_t)a.nseg * ncols);   // [2*nblocks]
+    const int tid = threadIdx.x;
+
+    if (MODE & COL_REDUCE) {
+        for (int i = tid; i < 2 * a.nblocks; i += COL_BLOCK) s_rng[i] = a.ranges[i];
+        __syncthreads();
+        for (int idx = tid; idx < a.nseg * ncols; idx += COL_BLOCK) {
+            const int seg = idx / ncols, col = idx - seg * ncols;
+            const int p = col / a.ncp, c = col - p * a.ncp;
+            const int b0 = (int)((long long)seg * a.nblocks / a.nseg);
+            const int b1 = (int)((long long)(seg + 1) * a.nblocks / a.nseg);
+            const double *src = a.partial + (size_t)p * a.ncp + c;
+            const size_t stride = (size_t)a.npay * a.ncp;
+            double acc = 0.0;
+            int b = b0;
+            for (; b + 8 <= b1; b += 8) {       // 8 independent loads in flight, fixed add order
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + u) * stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = (c >= s_rng[2 * (b + u)]) && (c < s_rng[2 * (b + u) + 1]);
+                    acc = acc + (in ? v[u] : 0.0);
+                }
+            }
+            for (; b < b1; ++b) {
+                const double v = src[(size_t)b * stride];
+                const bool in = (c >= s_rng[2 * b]) && (c < s_rng[2 * b + 1]);
+                acc = acc + (in ? v : 0.0);
+            }
+            s_seg[idx] = acc;
+        }
+        __syncthreads();
+        for (int col = tid; col < ncols; col += COL_BLOCK) {
+            double tot = s_seg[col];
+            for (int s = 1; s < a.nseg; ++s) tot = tot + s_seg[s * ncols + col];
+            a.flux[col] = tot;
+        }
+        if (!(MODE & COL_UPDATE)) return;
+        __syncthreads();
+    }
+
+    if (STAGE != 4) {
+        // pm_flux on interfaces, lib/libprop.py:653-660 (flux has ng-2 levels per component)
+        for (int i = tid; i < 2 * (ng - 2); i += COL_BLOCK) {
+            const int p = i / (ng - 2), c = i - p * (ng - 2);
+            s_F[p * ng + 1 + c] = a.flux[i];
+        }
+        __syncthreads();
+        if (tid < 2) { s_F[tid * ng] = s_F[tid * ng + 1]; s_F[tid * ng + ng - 1] = s_F[tid * ng + ng - 2]; }
+        __syncthreads();
+        if (STAGE == 3 && a.out_flux)
+            for (int i = tid; i < 2 * ng; i += COL_BLOCK) a.out_flux[i] = s_F[i];
+        for (int j = tid; j < nc; j += COL_BLOCK) {
+            const double gx = (s_F[j + 1] - s_F[j]) / a.dzg;                   // :663
+            const double gy = (s_F[ng + j + 1] - s_F[ng + j]) / a.dzg;
+            const double u = a.uu[j], v = a.vv[j];
+            const double rinv = 1.0 / a.rhobar[j];                              // rhobar**-1
+            double du = a.f0 * v - rinv * (a.pg[j] + gx);                       // :537
+            double dv = -a.f0 * u - rinv * (a.pg[nc + j] + gy);                 // :556
+            if (a.fixed_background) { du = 0.0; dv = 0.0; }
+            if (STAGE == 3) {
+                if (a.out_du) a.out_du[j] = du;
+                if (a.out_dv) a.out_dv[j] = dv;
+                s_u[j] = u; s_v[j] = v;
+            } else {
+                double qu, qv, un, vn;
+                if (STAGE == 0) {
+                    qu = a.dt * du; qv = a.dt * dv;
+                    un = u + qu / 3; vn = v + qv / 3;
+                } else if (STAGE == 1) {
+                    qu = a.dt * du - RK_A1 * a.q_uu[j]; qv = a.dt * dv - RK_A1 * a.q_vv[j];
+                    un = u + RK_B1 * qu; vn = v + RK_B1 * qv;
+                } else {
+                    qu = a.dt * du - RK_A2 * a.q_uu[j]; qv = a.dt * dv - RK_A2 * a.q_vv[j];
+                    un = u + RK_B2 * qu; vn = v + RK_B2 * qv;
+                }
+                a.q_uu[j] = qu; a.q_vv[j] = qv;
+                a.uu[j] = un; a.vv[j] = vn;
+                s_u[j] = un; s_v[j] = vn;
+            }
+        }
+        if (STAGE == 3) return;
+    } else {
+        for (int j = tid; j < nc; j += COL_BLOCK) { s_u[j] = a.uu[j]; s_v[j] = a.vv[j]; }
+    }
+    __syncthreads();
+    // shear on the interior interfaces, lib/libprop.py:352-353, and np.interp's slopes
+    for (int j = tid; j < ni; j += COL_BLOCK) {
+        const double du = (s_u[j + 1] - s_u[j]) / a.dzg;
+        const double dv = (s_v[j + 1] - s_v[j]) / a.dzg;
+        s_du[j] = du; s_dv[j] = dv;
+        a.dudz[j] = du; a.dvdz[j] = dv;
+    }
+    __syncthreads();
+    for (int j = tid; j < ni - 1; j += COL_BLOCK) {
+        const double dx = a.xg[j + 1] - a.xg[j];
+        a.slu[j] = (s_du[j + 1] - s_du[j]) / dx;
+        a.slv[j] = (s_dv[j + 1] - s_dv[j]) / dx;
+    }
+}
+
+// slopes of np.interp(., grids, rhobar) (lib/libprop.py:595), once per column upload
+__global__ void k_rho_slopes(int nc, const double *grids, const double *rhobar, double *slrho)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nc - 1) slrho[j] = (rhobar[j + 1] - rhobar[j]) / (grids[j + 1] - grids[j]);
+}
+
+}   // namespace msgw

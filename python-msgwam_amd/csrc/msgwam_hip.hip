@@ -1,0 +1,836 @@
+// C-ABI host side of the MI355X ray-propagation library (see include/msgwam_hip.h).
+// One context per GPU: SoA ray state + column resident in HBM, one HIP stream,
+// optional hipGraph of the RK3 step, optional RCCL communicator (dlopen'ed so
+// that the single-GPU path has no RCCL dependency).
+#include "msgwam_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "column_kernels.h"
+#include "ray_kernels.h"
+
+using namespace msgw;
+
+namespace {
+
+std::string g_create_error;
+
+// ---- minimal RCCL surface (resolved with dlsym; mirrors rccl.h) -------------
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { ncclFloat64 = 8, ncclSum = 0 };   // ncclDataType_t / ncclRedOp_t values in rccl.h
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string load_error;
+    bool load()
+    {
+        if (handle) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) {
+            handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) { load_error = std::string("dlopen librccl failed: ") + dlerror(); return false; }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(handle, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(handle, "ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+        AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce) {
+            load_error = "librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclAllReduce";
+            return false;
+        }
+        return true;
+    }
+} g_rccl;
+
+}   // namespace
+
+struct msgw_ctx {
+    int device = 0;
+    int ncu = 256;
+    int64_t cap = 0, n = 0;
+    int ng = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    // config
+    bool have_config = false, have_column = false, have_rays = false;
+    double bvf = 0, f0 = 0, kappa = 0;
+    int sat_online = 0;
+
+    // rays
+    std::vector<double *> ray_bufs;
+    double *dens = nullptr, *rr = nullptr, *mm = nullptr, *drr = nullptr, *kk = nullptr, *ll = nullptr,
+           *dmm = nullptr, *vol = nullptr, *fray = nullptr, *pvf = nullptr, *q_rr = nullptr,
+           *q_mm = nullptr, *q_dens = nullptr, *rr0 = nullptr, *mm0 = nullptr;
+    bool fvec = false;
+    double f_uni = 0;
+
+    // column
+    double *colbuf = nullptr;
+    double *grid = nullptr, *grids = nullptr, *rhobar = nullptr, *pg = nullptr, *uu = nullptr,
+           *vv = nullptr, *q_uu = nullptr, *q_vv = nullptr, *dudz = nullptr, *dvdz = nullptr,
+           *slu = nullptr, *slv = nullptr, *slrho = nullptr, *flux = nullptr, *out_du = nullptr,
+           *out_dv = nullptr, *out_flux = nullptr;
+    double dzg = 0, dzs = 0, xg0 = 0, gs0 = 0;
+
+    // launch geometry + per-workgroup flux rows
+    int blocks_per_cu = 4;
+    int blocks = 0, tiles_per_block = 0;
+    double *partial = nullptr;
+    size_t partial_elems = 0;
+    int *ranges = nullptr;
+    int ranges_cap = 0;
+
+    // graph
+    int graph_steps = 0;
+    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr;
+    double g_dt = 0;
+    unsigned g_flags = 0;
+    int64_t g_n = -1;
+    int g_steps = 0;
+
+    // rccl
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+
+    // counters / kernel timing
+    msgw_counters_t cnt{};
+    std::vector<hipEvent_t> kev;
+    size_t kev_used = 0;
+};
+
+namespace {
+
+int fail(msgw_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), MSGW_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                \
+    } while (0)
+
+size_t stage_lds_bytes(int ng)
+{
+    const int ni = ng - 2, nc = ng - 1, ncp = ng - 2;
+    return sizeof(double) * (size_t)(5 * ni + 3 * nc + WAVES * 2 * ncp) + sizeof(int) * 2 * WAVES + 16;
+}
+size_t proj_lds_bytes(int nG, int np)
+{
+    return sizeof(double) * (size_t)(nG + WAVES * np * (nG - 1)) + sizeof(int) * 2 * WAVES + 16;
+}
+size_t col_lds_bytes(int ng, int nseg, int ncols, int nblocks)
+{
+    return sizeof(double) * (size_t)(2 * ng + 2 * (ng - 1) + 2 * (ng - 2) + (size_t)nseg * ncols) +
+           sizeof(int) * 2 * (size_t)nblocks + 16;
+}
+int pick_nseg(int ncols)
+{
+    int s = COL_BLOCK / (ncols > 0 ? ncols : 1);
+    return s < 1 ? 1 : (s > 8 ? 8 : s);
+}
+
+template <typename K>
+int ensure_lds(msgw_ctx *c, K kernel, size_t bytes)
+{
+    if (bytes > 160 * 1024)
+        return fail(c, MSGW_ERR_UNSUP, "column too large for LDS staging (%zu B needed, ngrid=%d)", bytes, c->ng);
+    if (bytes > 64 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MSGW_OK;
+}
+
+void geometry(msgw_ctx *c, int64_t n)
+{
+    const int64_t ntiles = (n + TILE - 1) / TILE;
+    const int64_t maxb = (int64_t)c->ncu * c->blocks_per_cu;
+    int64_t tpb = (ntiles + maxb - 1) / maxb;
+    if (tpb < 1) tpb = 1;
+    int64_t blocks = (ntiles + tpb - 1) / tpb;
+    if (blocks < 1) blocks = 1;
+    c->tiles_per_block = (int)tpb;
+    c->blocks = (int)blocks;
+}
+
+void drop_graph(msgw_ctx *c)
+{
+    if (c->gexec) { (void)hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    c->g_n = -1;
+}
+
+int ensure_partial(msgw_ctx *c, int blocks, size_t row_elems)
+{
+    const size_t need = (size_t)blocks * row_elems;
+    if (need > c->partial_elems) {
+        drop_graph(c);                               // a captured graph holds the old pointer
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->partial) HIPCHK(c, hipFree(c->partial));
+        c->partial = nullptr;
+        HIPCHK(c, hipMalloc(&c->partial, need * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->partial, 0, need * sizeof(double), c->stream));
+        c->partial_elems = need;
+    }
+    if (blocks > c->ranges_cap) {
+        drop_graph(c);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->ranges) HIPCHK(c, hipFree(c->ranges));
+        c->ranges = nullptr;
+        HIPCHK(c, hipMalloc(&c->ranges, sizeof(int) * 2 * (size_t)blocks));
+        HIPCHK(c, hipMemsetAsync(c->ranges, 0, sizeof(int) * 2 * (size_t)blocks, c->stream));
+        c->ranges_cap = blocks;
+    }
+    return MSGW_OK;
+}
+
+StageArgs make_stage_args(msgw_ctx *c, double dt, unsigned flags)
+{
+    StageArgs a{};
+    a.n = c->n;
+    a.ng = c->ng;
+    a.tiles_per_block = c->tiles_per_block;
+    a.dt = dt;
+    a.bvf2 = std::pow(c->bvf, 2.0);               // python `bvf ** 2` (lib/libprop.py:383)
+    a.f_uni = c->f_uni;
+    a.f0sq = std::pow(c->f0, 2.0);                // python `ff ** 2` with scalar ff (:601)
+    a.same_f = (!c->fvec && (c->f_uni * c->f_uni == a.f0sq)) ? 1 : 0;
+    a.sat_c = std::pow(c->kappa, 2.0) * .5;       // `kappa**2 * .5` (:601)
+    a.sat_rr_div = (flags & MSGW_DIRECT_SAT_QUIRK) ? 1.0 : dt;
+    a.xg0 = c->xg0; a.inv_dzg = 1.0 / c->dzg;
+    a.gs0 = c->gs0; a.inv_dzs = 1.0 / c->dzs;
+    a.dzs = c->dzs;
+    a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
+                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0};
+    a.c = ColPtrs{c->grid + 1, c->dudz, c->dvdz, c->slu, c->slv, c->grids, c->rhobar, c->slrho};
+    a.partial = c->partial;
+    a.ranges = c->ranges;
+    return a;
+}
+
+ColArgs make_col_args(msgw_ctx *c, double dt, unsigned flags)
+{
+    ColArgs a{};
+    a.ng = c->ng;
+    a.nblocks = c->blocks;
+    a.npay = 2;
+    a.ncp = c->ng - 2;
+    a.nseg = pick_nseg(a.npay * a.ncp);
+    a.fixed_background = (flags & MSGW_FIXED_BACKGROUND) ? 1 : 0;
+    a.dt = dt; a.f0 = c->f0; a.dzg = c->dzg;
+    a.partial = c->partial; a.ranges = c->ranges; a.flux = c->flux;
+    a.rhobar = c->rhobar; a.pg = c->pg;
+    a.uu = c->uu; a.vv = c->vv; a.q_uu = c->q_uu; a.q_vv = c->q_vv;
+    a.xg = c->grid + 1;
+    a.dudz = c->dudz; a.dvdz = c->dvdz; a.slu = c->slu; a.slv = c->slv;
+    a.out_du = c->out_du; a.out_dv = c->out_dv; a.out_flux = c->out_flux;
+    return a;
+}
+
+// ---- kernel dispatch --------------------------------------------------------
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
+int launch_stage_t(msgw_ctx *c, const StageArgs &a)
+{
+    const size_t lds = stage_lds_bytes(c->ng);
+    auto k = k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT>;
+    if (int rc = ensure_lds(c, k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return MSGW_OK;
+}
+
+// mode: 0 plain, 1 online saturation, 2 direct (driver) saturation
+template <int STAGE>
+int launch_stage(msgw_ctx *c, const StageArgs &a, int mode)
+{
+    const bool fv = c->fvec;
+    if (mode == 1) return fv ? launch_stage_t<STAGE, true, true, true, false>(c, a)
+                             : launch_stage_t<STAGE, true, false, true, false>(c, a);
+    if (mode == 2 && STAGE != 1) return fv ? launch_stage_t<STAGE, false, true, true, true>(c, a)
+                                           : launch_stage_t<STAGE, false, false, true, true>(c, a);
+    return fv ? launch_stage_t<STAGE, false, true, true, false>(c, a)
+              : launch_stage_t<STAGE, false, false, true, false>(c, a);
+}
+
+int launch_probe(msgw_ctx *c, const StageArgs &a, bool sat, bool deposit)
+{
+    const bool fv = c->fvec;
+#define P_(S, F, D) launch_stage_t<3, S, F, D, false>(c, a)
+    if (sat) {
+        if (fv) return deposit ? P_(true, true, true) : P_(true, true, false);
+        return deposit ? P_(true, false, true) : P_(true, false, false);
+    }
+    if (fv) return deposit ? P_(false, true, true) : P_(false, true, false);
+    return deposit ? P_(false, false, true) : P_(false, false, false);
+#undef P_
+}
+
+template <bool SAT, bool FVEC, bool DIRECT>
+int launch_fixed_t(msgw_ctx *c, const StageArgs &a)
+{
+    const size_t lds = stage_lds_bytes(c->ng);
+    auto k = k_ray_step_fixed<SAT, FVEC, DIRECT>;
+    if (int rc = ensure_lds(c, k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return MSGW_OK;
+}
+int launch_fixed(msgw_ctx *c, const StageArgs &a, int mode)
+{
+    const bool fv = c->fvec;
+    if (mode == 1) return fv ? launch_fixed_t<true, true, false>(c, a) : launch_fixed_t<true, false, false>(c, a);
+    if (mode == 2) return fv ? launch_fixed_t<false, true, true>(c, a) : launch_fixed_t<false, false, true>(c, a);
+    return fv ? launch_fixed_t<false, true, false>(c, a) : launch_fixed_t<false, false, false>(c, a);
+}
+
+template <int STAGE, int MODE>
+int launch_column_t(msgw_ctx *c, const ColArgs &a)
+{
+    const size_t lds = col_lds_bytes(a.ng, a.nseg, a.npay * a.ncp, a.nblocks);
+    auto k = k_column<STAGE, MODE>;
+    if (int rc = ensure_lds(c, k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(1), dim3(COL_BLOCK), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return MSGW_OK;
+}
+
+int allreduce_flux(msgw_ctx *c)
+{
+    const size_t count = (size_t)2 * (c->ng - 2);
+    ncclResult_t r = g_rccl.AllReduce(c->flux, c->flux, count, ncclFloat64, ncclSum, c->comm, c->stream);
+    if (r != 0)
+        return fail(c, MSGW_ERR_RCCL, "ncclAllReduce failed: %s",
+                    g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return MSGW_OK;
+}
+
+// flux finalise (+ all-reduce over the ranks) + mean-flow RK stage
+template <int STAGE>
+int column_stage(msgw_ctx *c, const ColArgs &a)
+{
+    if (c->nranks > 1) {
+        if (int rc = launch_column_t<STAGE, COL_REDUCE>(c, a)) return rc;
+        if (int rc = allreduce_flux(c)) return rc;
+        return launch_column_t<STAGE, COL_UPDATE>(c, a);
+    }
+    return launch_column_t<STAGE, COL_REDUCE | COL_UPDATE>(c, a);
+}
+
+hipEvent_t *timing_events(msgw_ctx *c)
+{
+    if (c->kev_used + 2 > c->kev.size()) {
+        const size_t old = c->kev.size();
+        c->kev.resize(old + 512);
+        for (size_t i = old; i < c->kev.size(); ++i)
+            if (hipEventCreate(&c->kev[i]) != hipSuccess) { c->kev.resize(i); return nullptr; }
+    }
+    hipEvent_t *p = &c->kev[c->kev_used];
+    c->kev_used += 2;
+    return p;
+}
+
+// Enqueue one RK3 step (lib/libprop.py:693-698) on the context's stream.
+int enqueue_step(msgw_ctx *c, double dt, unsigned flags, bool time_kernels)
+{
+    const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
+    const StageArgs sa = make_stage_args(c, dt, flags);
+    auto timed = [&](auto &&launch) -> int {
+        hipEvent_t *ev = time_kernels ? timing_events(c) : nullptr;
+        if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
+        if (int rc = launch()) return rc;
+        if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
+        return MSGW_OK;
+    };
+    if (flags & MSGW_FIXED_BACKGROUND)
+        return timed([&] { return launch_fixed(c, sa, mode); });
+    const ColArgs ca = make_col_args(c, dt, flags);
+    if (int rc = timed([&] { return launch_stage<0>(c, sa, mode); })) return rc;
+    if (int rc = column_stage<0>(c, ca)) return rc;
+    if (int rc = timed([&] { return launch_stage<1>(c, sa, mode); })) return rc;
+    if (int rc = column_stage<1>(c, ca)) return rc;
+    if (int rc = timed([&] { return launch_stage<2>(c, sa, mode); })) return rc;
+    return column_stage<2>(c, ca);
+}
+
+int ready(msgw_ctx *c)
+{
+    if (!c) return MSGW_ERR_ARG;
+    if (!c->have_config) return fail(c, MSGW_ERR_ARG, "msgw_set_config has not been called");
+    if (!c->have_column) return fail(c, MSGW_ERR_ARG, "msgw_set_column has not been called");
+    if (!c->have_rays) return fail(c, MSGW_ERR_ARG, "msgw_upload_rays has not been called");
+    return MSGW_OK;
+}
+
+}   // namespace
+
+// ============================================================================ C ABI
+extern "C" {
+
+int msgw_abi_version(void) { return MSGW_ABI_VERSION; }
+
+const char *msgw_last_error(const msgw_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
+{
+    if (!out) return fail(nullptr, MSGW_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (nray_cap < 1 || ngrid < 4) return fail(nullptr, MSGW_ERR_ARG, "need nray_cap >= 1 and ngrid >= 4");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, MSGW_ERR_NOGPU, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, MSGW_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return fail(nullptr, MSGW_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MSGW_ERR_NOGPU, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    msgw_ctx *c = new msgw_ctx();
+    c->device = device;
+    c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->cap = nray_cap;
+    c->ng = ngrid;
+#define CR(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int rc_ = fail(nullptr, MSGW_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); msgw_destroy(c); return rc_; } } while (0)
+    CR(hipSetDevice(device));
+    CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CR(hipEventCreate(&c->ev0));
+    CR(hipEventCreate(&c->ev1));
+    double **rp[] = {&c->dens, &c->rr, &c->mm, &c->drr, &c->kk, &c->ll, &c->dmm, &c->vol, &c->fray,
+                     &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0};
+    const size_t padded = ((size_t)nray_cap + 1) & ~(size_t)1;     // keep 16-B pairs in bounds
+    for (double **p : rp) {
+        CR(hipMalloc(p, padded * sizeof(double)));
+        c->ray_bufs.push_back(*p);
+    }
+    // column: one allocation carved into equally sized slots of ng doubles (+ 2 for the flux output)
+    const size_t slot = (size_t)ngrid + 2;
+    const int nslots = 18;
+    CR(hipMalloc(&c->colbuf, slot * nslots * sizeof(double) * 2));
+    CR(hipMemset(c->colbuf, 0, slot * nslots * sizeof(double) * 2));
+    double *b = c->colbuf;
+    c->grid = b; b += slot; c->grids = b; b += slot; c->rhobar = b; b += slot;
+    c->pg = b; b += 2 * slot; c->uu = b; b += slot; c->vv = b; b += slot;
+    c->q_uu = b; b += slot; c->q_vv = b; b += slot; c->dudz = b; b += slot; c->dvdz = b; b += slot;
+    c->slu = b; b += slot; c->slv = b; b += slot; c->slrho = b; b += slot;
+    c->flux = b; b += 2 * slot; c->out_du = b; b += slot; c->out_dv = b; b += slot;
+    c->out_flux = b; b += 2 * slot;
+#undef CR
+    c->cnt.ngrid = ngrid;
+    c->cnt.nranks = 1;
+    *out = c;
+    return MSGW_OK;
+}
+
+int msgw_destroy(msgw_ctx *c)
+{
+    if (!c) return MSGW_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
+    for (double *p : c->ray_bufs) (void)hipFree(p);
+    if (c->colbuf) (void)hipFree(c->colbuf);
+    if (c->partial) (void)hipFree(c->partial);
+    if (c->ranges) (void)hipFree(c->ranges);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return MSGW_OK;
+}
+
+int msgw_set_config(msgw_ctx *c, double bvf, double f0, double kappa, int saturate_online, int hprop)
+{
+    if (!c) return MSGW_ERR_ARG;
+    if (hprop)
+        return fail(c, MSGW_ERR_UNSUP, "HPROP_GLOBAL=True (horizontal propagation) is outside this library's scope");
+    c->bvf = bvf; c->f0 = f0; c->kappa = kappa; c->sat_online = saturate_online ? 1 : 0;
+    c->have_config = true;
+    drop_graph(c);
+    return MSGW_OK;
+}
+
+int msgw_set_column(msgw_ctx *c, const double *grid, const double *grids, const double *rhobar,
+                    const double *pgrad, const double *uu, const double *vv)
+{
+    if (!c || !grid || !grids || !rhobar || !pgrad || !uu || !vv) return fail(c, MSGW_ERR_ARG, "NULL column pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int ng = c->ng, nc = ng - 1;
+    const size_t B = sizeof(double);
+    HIPCHK(c, hipMemcpyAsync(c->grid, grid, ng * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->grids, grids, nc * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rhobar, rhobar, nc * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->pg, pgrad, 2 * nc * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->uu, uu, nc * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->vv, vv, nc * B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // host buffers are the caller's
+    c->dzg = grid[1] - grid[0];                      // np.diff(grid[:2])[0]  (lib/libprop.py:349, :662)
+    c->dzs = grids[1] - grids[0];                    // the same on grids     (:123 with G = grids)
+    c->xg0 = grid[1];
+    c->gs0 = grids[0];
+    if (!(c->dzg > 0) || !(c->dzs > 0)) return fail(c, MSGW_ERR_ARG, "grid must be increasing");
+    hipLaunchKernelGGL(k_rho_slopes, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, c->grids, c->rhobar, c->slrho);
+    HIPCHK(c, hipGetLastError());
+    ColArgs a = make_col_args(c, 0.0, 0);
+    a.nblocks = 0; a.nseg = 1;
+    if (int rc = launch_column_t<4, COL_UPDATE>(c, a)) return rc;
+    c->have_column = true;
+    return MSGW_OK;
+}
+
+int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *rr, const double *drr,
+                     const double *kk, const double *ll, const double *mm, const double *dmm,
+                     const double *fray, const double *dkk, const double *dll, const double *area)
+{
+    if (!c) return MSGW_ERR_ARG;
+    if (n < 1 || n > c->cap) return fail(c, MSGW_ERR_ARG, "n=%lld outside [1, cap=%lld]", (long long)n, (long long)c->cap);
+    if (!dens || !rr || !drr || !kk || !ll || !mm || !dmm || !fray || !dkk || !dll || !area)
+        return fail(c, MSGW_ERR_ARG, "NULL ray pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t B = (size_t)n * sizeof(double);
+    struct { double *d; const double *h; } cp[] = {
+        {c->dens, dens}, {c->rr, rr}, {c->drr, drr}, {c->kk, kk}, {c->ll, ll}, {c->mm, mm},
+        {c->dmm, dmm}, {c->fray, fray}, {c->q_rr, dkk}, {c->q_mm, dll}, {c->q_dens, area}};
+    for (auto &x : cp) HIPCHK(c, hipMemcpyAsync(x.d, x.h, B, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (long long)n,
+                       c->q_rr, c->q_mm, c->q_dens, c->drr, c->dmm, c->vol, c->pvf);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // a single latitude for all rays (the 1-D column case, raytracer.py:87) keeps f in a scalar
+    bool uni = true;
+    for (int64_t i = 1; i < n && uni; ++i) uni = (std::memcmp(&fray[i], &fray[0], sizeof(double)) == 0);
+    c->fvec = !uni;
+    c->f_uni = fray[0];
+    c->n = n;
+    geometry(c, n);
+    if (int rc = ensure_partial(c, c->blocks, (size_t)2 * (c->ng - 2))) return rc;
+    c->have_rays = true;
+    c->cnt.nray = n;
+    c->cnt.blocks = c->blocks;
+    drop_graph(c);
+    return MSGW_OK;
+}
+
+int msgw_set_tuning(msgw_ctx *c, int blocks_per_cu, int graph_steps)
+{
+    if (!c) return MSGW_ERR_ARG;
+    if (blocks_per_cu < 1 || blocks_per_cu > 32 || graph_steps < 0 || graph_steps > 64)
+        return fail(c, MSGW_ERR_ARG, "blocks_per_cu in [1,32], graph_steps in [0,64]");
+    c->blocks_per_cu = blocks_per_cu;
+    c->graph_steps = graph_steps;
+    drop_graph(c);
+    if (c->have_rays) {
+        geometry(c, c->n);
+        if (int rc = ensure_partial(c, c->blocks, (size_t)2 * (c->ng - 2))) return rc;
+        c->cnt.blocks = c->blocks;
+    }
+    return MSGW_OK;
+}
+
+int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
+{
+    if (int rc = ready(c)) return rc;
+    if (nsteps < 0) return fail(c, MSGW_ERR_ARG, "nsteps < 0");
+    if ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) && c->sat_online)
+        flags &= ~(MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK);      // raytracer.py:182: only if not online
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool time_kernels = (flags & MSGW_TIME_KERNELS) != 0;
+    const bool eager = time_kernels || (flags & MSGW_NO_GRAPH) || c->graph_steps == 0;
+    const unsigned gflags = flags & ~(MSGW_NO_GRAPH | MSGW_TIME_KERNELS);
+    if (time_kernels) c->kev_used = 0;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    int done = 0;
+    if (!eager && nsteps >= c->graph_steps) {
+        if (!c->gexec || c->g_dt != dt || c->g_flags != gflags || c->g_n != c->n || c->g_steps != c->graph_steps) {
+            drop_graph(c);
+            bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            int rc = MSGW_OK;
+            if (ok) {
+                for (int s = 0; s < c->graph_steps && rc == MSGW_OK; ++s) rc = enqueue_step(c, dt, gflags, false);
+                hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+                ok = (rc == MSGW_OK) && (e == hipSuccess) && c->graph;
+            }
+            if (ok) ok = hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0) == hipSuccess;
+            if (!ok) {                       // capture unsupported (e.g. a collective): stay eager
+                (void)hipGetLastError();
+                drop_graph(c);
+                c->graph_steps = 0;
+            } else {
+                c->g_dt = dt; c->g_flags = gflags; c->g_n = c->n; c->g_steps = c->graph_steps;
+            }
+        }
+        while (c->gexec && nsteps - done >= c->g_steps) {
+            HIPCHK(c, hipGraphLaunch(c->gexec, c->stream));
+            done += c->g_steps;
+        }
+    }
+    for (; done < nsteps; ++done)
+        if (int rc = enqueue_step(c, dt, gflags, time_kernels)) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
+    c->cnt.graph_steps = c->gexec ? c->g_steps : 0;
+    if (time_kernels) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i + 1 < c->kev_used; i += 2) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->kev[i], c->kev[i + 1]));
+            c->cnt.ray_kernel_ms_sum += ms;
+            c->cnt.ray_kernel_launches += 1;
+        }
+    }
+    return MSGW_OK;
+}
+
+int msgw_rhs(msgw_ctx *c, double dt, unsigned flags, double *st_dens, double *st_rr, double *st_mm,
+             double *st_uu, double *st_vv, double *pm_flux)
+{
+    if (int rc = ready(c)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    const StageArgs sa = make_stage_args(c, dt, flags);
+    if (int rc = launch_probe(c, sa, c->sat_online != 0, true)) return rc;
+    const ColArgs ca = make_col_args(c, dt, flags);
+    if (int rc = column_stage<3>(c, ca)) return rc;
+    const size_t B = (size_t)c->n * sizeof(double), nc = c->ng - 1;
+    if (st_dens) HIPCHK(c, hipMemcpyAsync(st_dens, c->q_dens, B, hipMemcpyDeviceToHost, c->stream));
+    if (st_rr) HIPCHK(c, hipMemcpyAsync(st_rr, c->q_rr, B, hipMemcpyDeviceToHost, c->stream));
+    if (st_mm) HIPCHK(c, hipMemcpyAsync(st_mm, c->q_mm, B, hipMemcpyDeviceToHost, c->stream));
+    if (st_uu) HIPCHK(c, hipMemcpyAsync(st_uu, c->out_du, nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (st_vv) HIPCHK(c, hipMemcpyAsync(st_vv, c->out_dv, nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pm_flux) HIPCHK(c, hipMemcpyAsync(pm_flux, c->out_flux, 2 * (size_t)c->ng * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSGW_OK;
+}
+
+// shared tail of the two projection entry points: launch k_project on `a`, reduce, copy out
+static int run_projection(msgw_ctx *c, ProjArgs &a, bool expl, int np, const double *G, int nG, double *out)
+{
+    const int ncp = nG - 1;
+    double *dG = nullptr, *dflux = nullptr;
+    HIPCHK(c, hipMalloc(&dG, sizeof(double) * (size_t)nG));
+    if (hipMalloc(&dflux, sizeof(double) * (size_t)np * ncp) != hipSuccess) {
+        (void)hipFree(dG);
+        return fail(c, MSGW_ERR_HIP, "hipMalloc failed in projection");
+    }
+    int rc = MSGW_OK;
+    do {
+        if (hipMemcpyAsync(dG, G, sizeof(double) * (size_t)nG, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "H2D of G failed"); break; }
+        const int64_t ntiles = (a.n + TILE - 1) / TILE;
+        const int64_t maxb = (int64_t)c->ncu * c->blocks_per_cu;
+        int64_t tpb = (ntiles + maxb - 1) / maxb; if (tpb < 1) tpb = 1;
+        int blocks = (int)((ntiles + tpb - 1) / tpb); if (blocks < 1) blocks = 1;
+        a.tiles_per_block = (int)tpb;
+        if ((rc = ensure_partial(c, blocks, (size_t)np * ncp))) break;
+        a.G = dG; a.partial = c->partial; a.ranges = c->ranges;
+        const size_t lds = proj_lds_bytes(nG, np);
+#define LP_(NP, FV, EX) do { auto k = k_project<NP, FV, EX>; if ((rc = ensure_lds(c, k, lds))) break; \
+            hipLaunchKernelGGL(k, dim3(blocks), dim3(BLOCK), lds, c->stream, a); } while (0)
+        if (expl) { if (np == 2) LP_(2, true, true); else LP_(1, true, true); }
+        else if (np == 2) { if (c->fvec) LP_(2, true, false); else LP_(2, false, false); }
+        else { if (c->fvec) LP_(1, true, false); else LP_(1, false, false); }
+#undef LP_
+        if (rc) break;
+        if (hipGetLastError() != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "k_project launch failed"); break; }
+        ColArgs ca{};
+        ca.ng = 4; ca.nblocks = blocks; ca.npay = np; ca.ncp = ncp; ca.nseg = pick_nseg(np * ncp);
+        ca.partial = c->partial; ca.ranges = c->ranges; ca.flux = dflux;
+        if ((rc = launch_column_t<4, COL_REDUCE>(c, ca))) break;
+        if (hipMemcpyAsync(out, dflux, sizeof(double) * (size_t)np * ncp, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "D2H of projection failed"); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "sync failed in projection"); break; }
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(dG);
+    (void)hipFree(dflux);
+    return rc;
+}
+
+int msgw_project(msgw_ctx *c, int var, const double *G, int nG, double *out)
+{
+    if (int rc = ready(c)) return rc;
+    if (var < 0 || var > 2) return fail(c, MSGW_ERR_UNSUP, "wave_projection var=%d: only 0, 1, 2 have callers", var);
+    if (!G || !out || nG < 3) return fail(c, MSGW_ERR_ARG, "bad projection grid");
+    HIPCHK(c, hipSetDevice(c->device));
+    ProjArgs a{};
+    a.n = c->n; a.nG = nG; a.var = var;
+    a.bvf2 = std::pow(c->bvf, 2.0); a.f_uni = c->f_uni; a.dz = G[1] - G[0];
+    a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
+                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0};
+    return run_projection(c, a, false, var == 0 ? 2 : 1, G, nG, out);
+}
+
+int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const double *dens,
+                        const double *rr_low, const double *rr_up, const double *kk, const double *ll,
+                        const double *mm_low, const double *mm_up, const double *dkk, const double *dll,
+                        const double *dmm, const double *fray, const double *G, int nG, double *out)
+{
+    if (!c) return MSGW_ERR_ARG;
+    if (var < 0 || var > 2) return fail(c, MSGW_ERR_UNSUP, "wave_projection var=%d: only 0, 1, 2 have callers", var);
+    if (n < 1 || !G || !out || nG < 3) return fail(c, MSGW_ERR_ARG, "bad projection arguments");
+    const double *h[11] = {dens, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, fray};
+    for (const double *p : h) if (!p) return fail(c, MSGW_ERR_ARG, "NULL array");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t padded = ((size_t)n + 1) & ~(size_t)1;
+    double *buf = nullptr;
+    HIPCHK(c, hipMalloc(&buf, sizeof(double) * padded * 11));
+    int rc = MSGW_OK;
+    const double *d[11];
+    for (int i = 0; i < 11 && rc == MSGW_OK; ++i) {
+        d[i] = buf + padded * i;
+        if (hipMemcpyAsync(buf + padded * i, h[i], sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            rc = fail(c, MSGW_ERR_HIP, "H2D failed in msgw_project_arrays");
+    }
+    if (rc == MSGW_OK) {
+        ProjArgs a{};
+        a.n = n; a.nG = nG; a.var = var;
+        a.bvf2 = std::pow(bvf, 2.0); a.f_uni = 0.0; a.dz = G[1] - G[0];
+        a.e = ProjExplicit{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]};
+        rc = run_projection(c, a, true, var == 0 ? 2 : 1, G, nG, out);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(buf);
+    return rc;
+}
+
+int msgw_saturation(msgw_ctx *c, int64_t n, double dt, int direct, const double *dens,
+                    const double *rr_center, const double *rr_center_st, const double *drr,
+                    const double *drr_st, const double *kk, const double *ll, const double *mm_center,
+                    const double *mm_center_st, const double *dkk, const double *dll,
+                    const double *area, double *out)
+{
+    if (!c) return MSGW_ERR_ARG;
+    if (!c->have_config || !c->have_column) return fail(c, MSGW_ERR_ARG, "msgw_saturation needs set_config and set_column first");
+    if (n < 1 || !out) return fail(c, MSGW_ERR_ARG, "bad saturation arguments");
+    const double *h[12] = {dens, rr_center, rr_center_st, drr, drr_st, kk, ll, mm_center, mm_center_st, dkk, dll, area};
+    for (const double *p : h) if (!p) return fail(c, MSGW_ERR_ARG, "NULL array");
+    HIPCHK(c, hipSetDevice(c->device));
+    double *buf = nullptr;
+    HIPCHK(c, hipMalloc(&buf, sizeof(double) * (size_t)n * 13));
+    int rc = MSGW_OK;
+    for (int i = 0; i < 12 && rc == MSGW_OK; ++i)
+        if (hipMemcpyAsync(buf + (size_t)n * i, h[i], sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            rc = fail(c, MSGW_ERR_HIP, "H2D failed in msgw_saturation");
+    if (rc == MSGW_OK) {
+        SatArgs a{};
+        a.n = n; a.nc = c->ng - 1; a.direct = direct ? 1 : 0; a.dt = dt;
+        a.bvf2 = std::pow(c->bvf, 2.0); a.f0sq = std::pow(c->f0, 2.0); a.sat_c = std::pow(c->kappa, 2.0) * .5;
+        a.gs0 = c->gs0; a.inv_dzs = 1.0 / c->dzs;
+        const double *b = buf;
+        a.dens = b; a.rr = b + n; a.rr_st = b + 2 * n; a.drr = b + 3 * n; a.drr_st = b + 4 * n;
+        a.kk = b + 5 * n; a.ll = b + 6 * n; a.mm = b + 7 * n; a.mm_st = b + 8 * n;
+        a.dkk = b + 9 * n; a.dll = b + 10 * n; a.area = b + 11 * n;
+        a.grids = c->grids; a.rhobar = c->rhobar; a.slrho = c->slrho;
+        a.out = buf + (size_t)n * 12;
+        hipLaunchKernelGGL(k_saturation, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, a);
+        if (hipGetLastError() != hipSuccess) rc = fail(c, MSGW_ERR_HIP, "k_saturation launch failed");
+        else if (hipMemcpyAsync(out, a.out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+            rc = fail(c, MSGW_ERR_HIP, "D2H failed in msgw_saturation");
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == MSGW_OK) rc = fail(c, MSGW_ERR_HIP, "sync failed in msgw_saturation");
+    (void)hipFree(buf);
+    return rc;
+}
+
+int msgw_download_rays(msgw_ctx *c, int64_t n, double *dens, double *rr, double *mm)
+{
+    if (!c || !c->have_rays) return fail(c, MSGW_ERR_ARG, "no rays resident");
+    if (n != c->n) return fail(c, MSGW_ERR_ARG, "n=%lld but %lld rays are resident", (long long)n, (long long)c->n);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t B = (size_t)n * sizeof(double);
+    if (dens) HIPCHK(c, hipMemcpyAsync(dens, c->dens, B, hipMemcpyDeviceToHost, c->stream));
+    if (rr) HIPCHK(c, hipMemcpyAsync(rr, c->rr, B, hipMemcpyDeviceToHost, c->stream));
+    if (mm) HIPCHK(c, hipMemcpyAsync(mm, c->mm, B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSGW_OK;
+}
+
+int msgw_download_column(msgw_ctx *c, double *uu, double *vv)
+{
+    if (!c || !c->have_column) return fail(c, MSGW_ERR_ARG, "no column resident");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t B = (size_t)(c->ng - 1) * sizeof(double);
+    if (uu) HIPCHK(c, hipMemcpyAsync(uu, c->uu, B, hipMemcpyDeviceToHost, c->stream));
+    if (vv) HIPCHK(c, hipMemcpyAsync(vv, c->vv, B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSGW_OK;
+}
+
+int msgw_sync(msgw_ctx *c)
+{
+    if (!c) return MSGW_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSGW_OK;
+}
+
+int msgw_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(nullptr, MSGW_ERR_ARG, "id128 is NULL");
+    if (!g_rccl.load()) return fail(nullptr, MSGW_ERR_RCCL, "%s", g_rccl.load_error.c_str());
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != 0) return fail(nullptr, MSGW_ERR_RCCL, "ncclGetUniqueId failed (%d)", r);
+    std::memcpy(id128, &id, sizeof id);
+    return MSGW_OK;
+}
+
+int msgw_comm_init(msgw_ctx *c, const void *id128, int rank, int nranks)
+{
+    if (!c || !id128) return fail(c, MSGW_ERR_ARG, "NULL argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MSGW_ERR_ARG, "bad rank %d / %d", rank, nranks);
+    if (!g_rccl.load()) return fail(c, MSGW_ERR_RCCL, "%s", g_rccl.load_error.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+    if (r != 0)
+        return fail(c, MSGW_ERR_RCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    c->rank = rank;
+    c->nranks = nranks;
+    c->cnt.nranks = nranks;
+    drop_graph(c);
+    return MSGW_OK;
+}
+
+int msgw_counters(msgw_ctx *c, msgw_counters_t *out)
+{
+    if (!c || !out) return MSGW_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->cnt.ray_steps_total > 0) {
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->cnt.last_step_ms = ms;
+    }
+    *out = c->cnt;
+    return MSGW_OK;
+}
+
+}   // extern "C"

@@ -1,0 +1,681 @@
+// Device code of the ray-propagation path, written for CDNA4 / gfx950 only
+// (wave64, DPP cross-lane reduction, LDS-staged column, 16-B/lane coalesced
+// SoA loads).  Compiled with -ffp-contract=off: every expression below is in
+// the reference's (numpy's) evaluation order so that per-ray results are
+// bit-comparable with lib/libprop.py.  Citations are reference file:line.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstdint>
+
+namespace msgw {
+
+constexpr int BLOCK = 256;           // 4 wavefronts
+constexpr int WAVES = BLOCK / 64;
+constexpr int RPT = 2;               // rays per lane -> 16-B global accesses
+constexpr int TILE = BLOCK * RPT;    // rays per workgroup iteration
+constexpr int SPAN_MAX = 8;          // widest per-wave level span on the shuffle path
+constexpr int COL_BLOCK = 1024;      // the column kernel is one workgroup
+
+// Williamson RK3 as python evaluates it (lib/libprop.py:693-698)
+constexpr double RK_A1 = 5.0 / 9.0;
+constexpr double RK_A2 = 153.0 / 128.0;
+constexpr double RK_B1 = 15.0 / 16.0;
+constexpr double RK_B2 = 8.0 / 15.0;
+
+struct RayPtrs {
+    double *dens, *rr, *mm;                        // evolving slots 0, 3, 7
+    const double *drr, *kk, *ll, *dmm;             // frozen slots 4, 5, 6, 8 (HPROP off)
+    const double *vol;                             // |dkk*dll*dmm|            (:137)
+    const double *fray;                            // 2*Omega*sin(phi) per ray (:382)
+    const double *pvf;                             // dkk*dll*(rr_mm_area/drr) (:594, :599)
+    double *q_rr, *q_mm, *q_dens;                  // low-storage RK registers
+    double *rr0, *mm0;                             // start-of-step copies (direct saturation)
+};
+
+struct ColPtrs {
+    const double *xg;                              // grid[1:-1], ni = ng-2
+    const double *dudz, *dvdz;                     // first differences on xg (:352-353)
+    const double *slu, *slv;                       // np.interp slopes, ni-1
+    const double *grids, *rhobar, *slrho;          // nc = ng-1 (slopes nc-1)
+};
+
+struct StageArgs {
+    long long n;
+    int ng;
+    int tiles_per_block;
+    double dt;
+    double bvf2;          // bvf**2
+    double f_uni;         // per-ray f when it is the same for every ray
+    double f0sq;          // (2*Omega*sin(phi0))**2, config latitude (:589, :597)
+    int same_f;           // f_uni*f_uni == f0sq  -> omh == om
+    double sat_c;         // kappa**2 * .5
+    double sat_rr_div;    // 1.0 (driver quirk raytracer.py:184) or dt
+    double xg0, inv_dzg;  // index guess on xg
+    double gs0, inv_dzs;  // index guess on grids
+    double dzs;           // grids[1]-grids[0]  (:123 with G = grids)
+    RayPtrs r;
+    ColPtrs c;
+    double *partial;      // [blocks][2][ng-2] per-workgroup flux rows
+    int *ranges;          // [blocks][2] touched level range of each row
+};
+
+// ------------------------------------------------------------------ cross-lane
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(dpp_i32<CTRL>(hi), dpp_i32<CTRL>(lo));
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// Sum over the 64 lanes in a FIXED order (xor 1, xor 2, half-mirror, mirror
+// inside each 16-lane row, then the four rows): bit-reproducible, no LDS.
+// Must be called with all 64 lanes active.
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = v + dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v = v + dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v = v + dpp_f64<0x141>(v);    // row_half_mirror
+    v = v + dpp_f64<0x140>(v);    // row_mirror
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16);
+    const double r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ int wave_min(int v)
+{
+    v = min(v, dpp_i32<0xB1>(v));
+    v = min(v, dpp_i32<0x4E>(v));
+    v = min(v, dpp_i32<0x141>(v));
+    v = min(v, dpp_i32<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+    v = max(v, dpp_i32<0xB1>(v));
+    v = max(v, dpp_i32<0x4E>(v));
+    v = max(v, dpp_i32<0x141>(v));
+    v = max(v, dpp_i32<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// ------------------------------------------------------------------ global access
+__device__ __forceinline__ void load2(const double *p, long long i0, bool v0, bool v1,
+                                      double (&out)[2], double fill)
+{
+    if (v1) {
+        const double2 t = *reinterpret_cast<const double2 *>(p + i0);   // 16 B per lane
+        out[0] = t.x; out[1] = t.y;
+    } else {
+        out[0] = v0 ? p[i0] : fill;
+        out[1] = fill;
+    }
+}
+__device__ __forceinline__ void store2(double *p, long long i0, bool v0, bool v1,
+                                       const double (&v)[2])
+{
+    if (v1) *reinterpret_cast<double2 *>(p + i0) = make_double2(v[0], v[1]);
+    else if (v0) p[i0] = v[0];
+}
+
+// ------------------------------------------------------------------ np.interp on an LDS column
+// numpy's arr_interp (the arithmetic behind lib/libprop.py:355-356, :595):
+// end values outside [xp[0], xp[n-1]], fp[j] exactly when x == xp[j], otherwise
+// slope[j]*(x - xp[j]) + fp[j] with slope[j] = (fp[j+1]-fp[j])/(xp[j+1]-xp[j])
+// (precomputed by the column kernel with the same expression).
+// Returns the bracket index j (0..n-1) and a mode: 0 interior, 1 take fp[j].
+__device__ __forceinline__ int interp_locate(double x, const double *xp, int n,
+                                             double x0, double inv_dx, int &mode)
+{
+    if (x > xp[n - 1]) { mode = 1; return n - 1; }
+    if (x < xp[0]) { mode = 1; return 0; }
+    int j = (int)((x - x0) * inv_dx);              // uniform-grid guess, then exact fix-up
+    j = min(max(j, 0), n - 1);
+    while (j > 0 && x < xp[j]) --j;
+    while (j < n - 1 && x >= xp[j + 1]) ++j;
+    mode = (j == n - 1 || x == xp[j]) ? 1 : 0;
+    return j;
+}
+__device__ __forceinline__ double interp_eval(double x, int j, int mode, const double *xp,
+                                              const double *fp, const double *sl)
+{
+    if (x != x) return x;                          // NaN in -> NaN out
+    if (mode) return fp[j];
+    return sl[j] * (x - xp[j]) + fp[j];
+}
+
+// numpy `.astype(int)` on x86-64 (lib/libprop.py:124-125) kept in the double
+// domain: truncation toward zero; NaN/inf/out-of-range behave as INT64_MIN.
+__device__ __forceinline__ double np_trunc_index(double t)
+{
+    return (fabs(t) < 9.2233720368547758e18) ? trunc(t) : -9.3e18;
+}
+
+// ------------------------------------------------------------------ deposit (wave_projection)
+// lib/libprop.py:123-163.  Each lane holds RPT rays with extent [lo, up],
+// NP payload values and the phase-space volume.  Levels are accumulated per
+// WAVE into that wave's private LDS row (plain read-modify-write by lane 0, so
+// the order is fixed), after a DPP reduction over the 64 lanes per level.  If
+// the wave's rays span more than SPAN_MAX levels (unsorted input) the lanes
+// fall back to LDS float64 atomics on the same private row.
+template <int NP>
+__device__ __forceinline__ void deposit_indices(double lo, double up, bool valid, double dz,
+                                                int nzmax, int &nlo, int &nup)
+{
+    const double nl = np_trunc_index(lo / dz);               // :124
+    const double nu = np_trunc_index(up / dz + 1.);          // :125
+    const double nz = (double)nzmax;                         // :127
+    const bool ood = ((nl >= nz) && (nu >= nz)) || ((nl <= 0.0) && (nu <= 0.0));   // :129-130
+    nlo = (int)fmin(fmax(nl, 0.0), nz);                      // :133-134
+    nup = (int)fmin(fmax(nu, 0.0), nz);
+    if (ood || !valid) { nlo = 0; nup = 0; }                 // :135, :153-154
+}
+
+template <int NP>
+__device__ __forceinline__ void deposit_tile(const double (&lo)[RPT], const double (&up)[RPT],
+                                             const int (&nlo)[RPT], const int (&nup)[RPT],
+                                             const double (&vol)[RPT], const double (&pay)[NP][RPT],
+                                             const double *sG, double dz, double *row, int ncp,
+                                             int lane, int &wmin, int &wmax)
+{
+    int mylo = INT_MAX, myhi = INT_MIN;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+        if (nup[r] > nlo[r]) { mylo = min(mylo, nlo[r]); myhi = max(myhi, nup[r]); }
+    const int wlo = wave_min(mylo), whi = wave_max(myhi);    // wave-uniform
+    if (whi <= wlo) return;
+    wmin = min(wmin, wlo);
+    wmax = max(wmax, whi);
+    if (whi - wlo <= SPAN_MAX) {
+        for (int c = wlo; c < whi; ++c) {                    // uniform trip count: all lanes stay
+            const double g0 = sG[c], g1 = sG[c + 1];         // LDS broadcast reads
+            double s[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) s[p] = 0.0;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                if (c >= nlo[r] && c < nup[r]) {
+                    const double zmin = (g0 > lo[r]) ? g0 : lo[r];          // :157
+                    const double zmax = (g1 < up[r]) ? g1 : up[r];          // :158
+                    const double wv = (fabs(zmax - zmin) / dz) * vol[r];    // :160, :162
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) s[p] = s[p] + wv * pay[p][r];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const double t = wave_sum(s[p]);
+                if (lane == 0) row[p * ncp + c] += t;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            for (int c = nlo[r]; c < nup[r]; ++c) {
+                const double g0 = sG[c], g1 = sG[c + 1];
+                const double zmin = (g0 > lo[r]) ? g0 : lo[r];
+                const double zmax = (g1 < up[r]) ? g1 : up[r];
+                const double wv = (fabs(zmax - zmin) / dz) * vol[r];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    __hip_atomic_fetch_add(&row[p * ncp + c], wv * pay[p][r], __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
+// Sum the WAVES private rows in wave order and write this workgroup's row
+// (only the touched level range) plus the range descriptor.
+template <int NP>
+__device__ __forceinline__ void flush_rows(const double *rows, int ncp, int *s_rng, int wave,
+                                           int lane, int tid, int wmin, int wmax,
+                                           double *partial, int *ranges)
+{
+    if (lane == 0) { s_rng[2 * wave] = wmin; s_rng[2 * wave + 1] = wmax; }
+    __syncthreads();
+    int bmin = INT_MAX, bmax = INT_MIN;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { bmin = min(bmin, s_rng[2 * w]); bmax = max(bmax, s_rng[2 * w + 1]); }
+    if (bmax <= bmin) { bmin = 0; bmax = 0; }
+    double *prow = partial + (size_t)blockIdx.x * NP * ncp;
+    const int span = bmax - bmin;
+    for (int i = tid; i < NP * span; i += BLOCK) {
+        const int p = i / span, c = bmin + (i - p * span);
+        double acc = rows[(0 * NP + p) * ncp + c];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) acc = acc + rows[(w * NP + p) * ncp + c];
+        prow[p * ncp + c] = acc;
+    }
+    if (tid == 0) { ranges[2 * blockIdx.x] = bmin; ranges[2 * blockIdx.x + 1] = bmax; }
+}
+
+// ------------------------------------------------------------------ dispersion
+// omega :383 and cg_rr :445-448 sharing sub-expressions (numpy recomputes the
+// identical values; sharing them is bit-neutral).
+__device__ __forceinline__ void dispersion(double kk, double ll, double mm, double f2, double bvf2,
+                                           double &kh2, double &m2, double &vk2, double &om,
+                                           double &cgr)
+{
+    kh2 = kk * kk + ll * ll;
+    m2 = mm * mm;
+    vk2 = kh2 + m2;
+    om = sqrt((bvf2 * kh2 + f2 * m2) / vk2);
+    cgr = -mm * (om * om - f2) / om / vk2;
+}
+
+// saturation cap :601 (rho_f already interpolated)
+__device__ __forceinline__ double sat_cap(double sat_c, double rho_f, double omh, double bvf2,
+                                          double mm_f, double f0sq)
+{
+    return sat_c * rho_f * omh * bvf2 / (mm_f * mm_f) / (omh * omh - f0sq);
+}
+
+// ------------------------------------------------------------------ K1: one RK stage over the rays
+// STAGE 0,1,2: rhs_default (:618-651) + low-storage RK update (:693-698) of rr,
+// mm (and dens when SAT) + pseudo-momentum-flux deposit (:654-658) of the
+// stage's INPUT state.  STAGE 3: tendencies only, written to the q arrays
+// (single-RHS probe).  DIRECT: the driver's post-step saturation
+// (raytracer.py:182-188) fused into stage 2 (stage 0 keeps rr, mm copies).
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
+__global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
+{
+    extern __shared__ double lds[];
+    const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
+    constexpr bool NEED_RHO = SAT || (DIRECT && STAGE == 2);
+    double *s_xg = lds, *s_dudz = s_xg + ni, *s_dvdz = s_dudz + ni, *s_slu = s_dvdz + ni,
+           *s_slv = s_slu + ni;
+    double *s_gs = s_slv + ni;                               // [nc]   (DEPOSIT or NEED_RHO)
+    double *s_rho = s_gs + nc, *s_slrho = s_rho + nc;        // [nc] each (NEED_RHO)
+    double *s_rows = s_slrho + nc;                           // [WAVES][2][ncp] (DEPOSIT)
+    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * 2 * ncp);
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < ni; i += BLOCK) {
+        s_xg[i] = a.c.xg[i]; s_dudz[i] = a.c.dudz[i]; s_dvdz[i] = a.c.dvdz[i];
+        if (i < ni - 1) { s_slu[i] = a.c.slu[i]; s_slv[i] = a.c.slv[i]; }
+    }
+    if (DEPOSIT || NEED_RHO)
+        for (int i = tid; i < nc; i += BLOCK) s_gs[i] = a.c.grids[i];
+    if (NEED_RHO)
+        for (int i = tid; i < nc; i += BLOCK) {
+            s_rho[i] = a.c.rhobar[i];
+            if (i < nc - 1) s_slrho[i] = a.c.slrho[i];
+        }
+    if (DEPOSIT)
+        for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) s_rows[i] = 0.0;
+    __syncthreads();
+
+    int wmin = INT_MAX, wmax = INT_MIN;
+    const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
+    for (int t = 0; t < a.tiles_per_block; ++t) {
+        const long long base = (tile0 + t) * (long long)TILE;
+        if (base >= a.n) break;                              // workgroup-uniform
+        const long long i0 = base + 2 * tid;
+        const bool v0 = i0 < a.n, v1 = i0 + 1 < a.n;
+        const bool valid[2] = {v0, v1};
+
+        double rr[2], mm[2], kk[2], ll[2], dens[2], drr[2], vol[2], ff[2], pvf[2];
+        double qr[2], qm[2], qd[2], rr0[2], mm0[2];
+        load2(a.r.rr, i0, v0, v1, rr, 0.0);
+        load2(a.r.mm, i0, v0, v1, mm, 1.0);
+        load2(a.r.kk, i0, v0, v1, kk, 1.0);
+        load2(a.r.ll, i0, v0, v1, ll, 0.0);
+        if (DEPOSIT || SAT || (DIRECT && STAGE == 2)) load2(a.r.dens, i0, v0, v1, dens, 0.0);
+        if (DEPOSIT) { load2(a.r.drr, i0, v0, v1, drr, 1.0); load2(a.r.vol, i0, v0, v1, vol, 0.0); }
+        if (FVEC) load2(a.r.fray, i0, v0, v1, ff, 0.0);
+        if (NEED_RHO) load2(a.r.pvf, i0, v0, v1, pvf, 1.0);
+        if (STAGE == 1 || STAGE == 2) {
+            load2(a.r.q_rr, i0, v0, v1, qr, 0.0);
+            load2(a.r.q_mm, i0, v0, v1, qm, 0.0);
+            if (SAT) load2(a.r.q_dens, i0, v0, v1, qd, 0.0);
+        }
+        if (DIRECT && STAGE == 2) {
+            load2(a.r.rr0, i0, v0, v1, rr0, 0.0);
+            load2(a.r.mm0, i0, v0, v1, mm0, 1.0);
+        }
+        if (DIRECT && STAGE == 0) {                          // keep the start-of-step rr, mm
+            store2(a.r.rr0, i0, v0, v1, rr);
+            store2(a.r.mm0, i0, v0, v1, mm);
+        }
+
+        double lo[2], up[2], pay[2][2], nrr[2], nmm[2], ndens[2];
+        int nlo[2], nup[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double f = FVEC ? ff[r] : a.f_uni;
+            const double f2 = f * f;
+            double kh2, m2, vk2, om, cgr;
+            dispersion(kk[r], ll[r], mm[r], f2, a.bvf2, kh2, m2, vk2, om, cgr);   // :635-636
+            const double st_rr = .5 * (cgr + cgr);                                  // :640
+            int mode;
+            const int j = interp_locate(rr[r], s_xg, ni, a.xg0, a.inv_dzg, mode);
+            const double gu = interp_eval(rr[r], j, mode, s_xg, s_dudz, s_slu);     // :355
+            const double gv = interp_eval(rr[r], j, mode, s_xg, s_dvdz, s_slv);     // :356
+            const double gradient = kk[r] * gu + ll[r] * gv;                        // :517
+            // :519-520: cg_lambda = cg_phi = 0 with HPROP off; the reference's division of that
+            // zero by (RAD_EARTH + rr) only matters for rr == -RAD_EARTH and is not reproduced.
+            const double st_mm = (kk[r] * 0.0 + ll[r] * 0.0) - gradient;
+            double st_dens = 0.0;
+            if (SAT) {                                                              // :647-651 -> :561-615
+                const double rr_f = rr[r] + st_rr * a.dt;                           // :591
+                const double mm_f = mm[r] + st_mm * a.dt;                           // :593
+                int md;
+                const int jr = interp_locate(rr_f, s_gs, nc, a.gs0, a.inv_dzs, md);
+                const double rho_f = interp_eval(rr_f, jr, md, s_gs, s_rho, s_slrho);   // :595
+                const double omh = a.same_f ? om : sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);   // :597
+                const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);  // :601
+                if (maxd < dens[r] * pvf[r]) st_dens = (maxd - dens[r]) / a.dt;     // :604, :613
+            }
+            if (DEPOSIT) {
+                lo[r] = rr[r] - .5 * drr[r];                                        // :655
+                up[r] = rr[r] + .5 * drr[r];
+                deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, nc - 2, nlo[r], nup[r]);
+                // :148-149.  The reference evaluates cg_rr at .5*((mm-.5*dmm)+(mm+.5*dmm)), which
+                // equals mm to within 1 ulp; the stage's own cgr is reused here.
+                pay[0][r] = cgr * kk[r] * dens[r];
+                pay[1][r] = cgr * ll[r] * dens[r];
+            }
+            if (STAGE == 3) {
+                nrr[r] = st_rr; nmm[r] = st_mm; ndens[r] = st_dens;
+            } else {
+                double q_r, q_m, q_d = 0.0;
+                if (STAGE == 0) {                                                   // :693-694
+                    q_r = a.dt * st_rr; q_m = a.dt * st_mm;
+                    nrr[r] = rr[r] + q_r / 3; nmm[r] = mm[r] + q_m / 3;
+                    if (SAT) { q_d = a.dt * st_dens; ndens[r] = dens[r] + q_d / 3; }
+                } else if (STAGE == 1) {                                            // :695-696
+                    q_r = a.dt * st_rr - RK_A1 * qr[r]; q_m = a.dt * st_mm - RK_A1 * qm[r];
+                    nrr[r] = rr[r] + RK_B1 * q_r; nmm[r] = mm[r] + RK_B1 * q_m;
+                    if (SAT) { q_d = a.dt * st_dens - RK_A1 * qd[r]; ndens[r] = dens[r] + RK_B1 * q_d; }
+                } else {                                                            // :697-698
+                    q_r = a.dt * st_rr - RK_A2 * qr[r]; q_m = a.dt * st_mm - RK_A2 * qm[r];
+                    nrr[r] = rr[r] + RK_B2 * q_r; nmm[r] = mm[r] + RK_B2 * q_m;
+                    if (SAT) { q_d = a.dt * st_dens - RK_A2 * qd[r]; ndens[r] = dens[r] + RK_B2 * q_d; }
+                }
+                qr[r] = q_r; qm[r] = q_m; qd[r] = q_d;
+                if (DIRECT && STAGE == 2) {                   // raytracer.py:182-188 -> :561-610
+                    const double d_in = SAT ? ndens[r] : dens[r];
+                    const double rr_st = (nrr[r] - rr0[r]) / a.sat_rr_div;          // raytracer.py:184
+                    const double mm_st = (nmm[r] - mm0[r]) / a.dt;                  // raytracer.py:187
+                    const double rr_f = rr0[r] + rr_st * a.dt;
+                    const double mm_f = mm0[r] + mm_st * a.dt;
+                    int md;
+                    const int jr = interp_locate(rr_f, s_gs, nc, a.gs0, a.inv_dzs, md);
+                    const double rho_f = interp_eval(rr_f, jr, md, s_gs, s_rho, s_slrho);
+                    const double m02 = mm0[r] * mm0[r];
+                    const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m02) / (kh2 + m02));   // :597 (old mm)
+                    const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
+                    ndens[r] = (maxd < d_in * pvf[r]) ? maxd : d_in;                // :604-608
+                }
+            }
+        }
+
+        if (STAGE == 3) {
+            store2(a.r.q_rr, i0, v0, v1, nrr);
+            store2(a.r.q_mm, i0, v0, v1, nmm);
+            store2(a.r.q_dens, i0, v0, v1, ndens);
+        } else {
+            store2(a.r.rr, i0, v0, v1, nrr);
+            store2(a.r.mm, i0, v0, v1, nmm);
+            if (SAT || (DIRECT && STAGE == 2)) store2(a.r.dens, i0, v0, v1, ndens);
+            if (STAGE != 2) {
+                store2(a.r.q_rr, i0, v0, v1, qr);
+                store2(a.r.q_mm, i0, v0, v1, qm);
+                if (SAT) store2(a.r.q_dens, i0, v0, v1, qd);
+            }
+        }
+        if (DEPOSIT)
+            deposit_tile<2>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, s_rows + wave * 2 * ncp, ncp,
+                            lane, wmin, wmax);
+    }
+    if (DEPOSIT)
+        flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
+}
+
+// ------------------------------------------------------------------ K1f: fixed background, whole RK3 step in registers
+// The rhs hook that zeroes slots 9, 10 (BASELINE configs 1, 2): no inter-ray
+// dependency, so the three stages run back to back per ray and rr, mm (dens)
+// touch HBM once per step.
+template <bool SAT, bool FVEC, bool DIRECT>
+__global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
+{
+    extern __shared__ double lds[];
+    const int ng = a.ng, ni = ng - 2, nc = ng - 1;
+    constexpr bool NEED_RHO = SAT || DIRECT;
+    double *s_xg = lds, *s_dudz = s_xg + ni, *s_dvdz = s_dudz + ni, *s_slu = s_dvdz + ni,
+           *s_slv = s_slu + ni;
+    double *s_gs = s_slv + ni, *s_rho = s_gs + nc, *s_slrho = s_rho + nc;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ni; i += BLOCK) {
+        s_xg[i] = a.c.xg[i]; s_dudz[i] = a.c.dudz[i]; s_dvdz[i] = a.c.dvdz[i];
+        if (i < ni - 1) { s_slu[i] = a.c.slu[i]; s_slv[i] = a.c.slv[i]; }
+    }
+    if (NEED_RHO)
+        for (int i = tid; i < nc; i += BLOCK) {
+            s_gs[i] = a.c.grids[i]; s_rho[i] = a.c.rhobar[i];
+            if (i < nc - 1) s_slrho[i] = a.c.slrho[i];
+        }
+    __syncthreads();
+
+    const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
+    for (int t = 0; t < a.tiles_per_block; ++t) {
+        const long long base = (tile0 + t) * (long long)TILE;
+        if (base >= a.n) break;
+        const long long i0 = base + 2 * tid;
+        const bool v0 = i0 < a.n, v1 = i0 + 1 < a.n;
+        double rr[2], mm[2], kk[2], ll[2], dens[2], ff[2], pvf[2];
+        load2(a.r.rr, i0, v0, v1, rr, 0.0);
+        load2(a.r.mm, i0, v0, v1, mm, 1.0);
+        load2(a.r.kk, i0, v0, v1, kk, 1.0);
+        load2(a.r.ll, i0, v0, v1, ll, 0.0);
+        if (FVEC) load2(a.r.fray, i0, v0, v1, ff, 0.0);
+        if (NEED_RHO) { load2(a.r.dens, i0, v0, v1, dens, 0.0); load2(a.r.pvf, i0, v0, v1, pvf, 1.0); }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double f = FVEC ? ff[r] : a.f_uni;
+            const double f2 = f * f;
+            const double kh2 = kk[r] * kk[r] + ll[r] * ll[r];
+            const double rr_old = rr[r], mm_old = mm[r];
+            double q_r = 0.0, q_m = 0.0, q_d = 0.0;
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                const double m2 = mm[r] * mm[r];
+                const double vk2 = kh2 + m2;
+                const double om = sqrt((a.bvf2 * kh2 + f2 * m2) / vk2);
+                const double cgr = -mm[r] * (om * om - f2) / om / vk2;
+                const double st_rr = .5 * (cgr + cgr);
+                int mode;
+                const int j = interp_locate(rr[r], s_xg, ni, a.xg0, a.inv_dzg, mode);
+                const double gu = interp_eval(rr[r], j, mode, s_xg, s_dudz, s_slu);
+                const double gv = interp_eval(rr[r], j, mode, s_xg, s_dvdz, s_slv);
+                const double st_mm = (kk[r] * 0.0 + ll[r] * 0.0) - (kk[r] * gu + ll[r] * gv);
+                double st_dens = 0.0;
+                if (SAT) {
+                    const double rr_f = rr[r] + st_rr * a.dt;
+                    const double mm_f = mm[r] + st_mm * a.dt;
+                    int md;
+                    const int jr = interp_locate(rr_f, s_gs, nc, a.gs0, a.inv_dzs, md);
+                    const double rho_f = interp_eval(rr_f, jr, md, s_gs, s_rho, s_slrho);
+                    const double omh = a.same_f ? om : sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);
+                    const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
+                    if (maxd < dens[r] * pvf[r]) st_dens = (maxd - dens[r]) / a.dt;
+                }
+                if (st == 0) {
+                    q_r = a.dt * st_rr; q_m = a.dt * st_mm;
+                    rr[r] = rr[r] + q_r / 3; mm[r] = mm[r] + q_m / 3;
+                    if (SAT) { q_d = a.dt * st_dens; dens[r] = dens[r] + q_d / 3; }
+                } else {
+                    const double A = (st == 1) ? RK_A1 : RK_A2, B = (st == 1) ? RK_B1 : RK_B2;
+                    q_r = a.dt * st_rr - A * q_r; q_m = a.dt * st_mm - A * q_m;
+                    rr[r] = rr[r] + B * q_r; mm[r] = mm[r] + B * q_m;
+                    if (SAT) { q_d = a.dt * st_dens - A * q_d; dens[r] = dens[r] + B * q_d; }
+                }
+            }
+            if (DIRECT) {
+                const double rr_st = (rr[r] - rr_old) / a.sat_rr_div;
+                const double mm_st = (mm[r] - mm_old) / a.dt;
+                const double rr_f = rr_old + rr_st * a.dt;
+                const double mm_f = mm_old + mm_st * a.dt;
+                int md;
+                const int jr = interp_locate(rr_f, s_gs, nc, a.gs0, a.inv_dzs, md);
+                const double rho_f = interp_eval(rr_f, jr, md, s_gs, s_rho, s_slrho);
+                const double m02 = mm_old * mm_old;
+                const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m02) / (kh2 + m02));
+                const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
+                if (maxd < dens[r] * pvf[r]) dens[r] = maxd;
+            }
+        }
+        store2(a.r.rr, i0, v0, v1, rr);
+        store2(a.r.mm, i0, v0, v1, mm);
+        if (NEED_RHO) store2(a.r.dens, i0, v0, v1, dens);
+    }
+}
+
+// ------------------------------------------------------------------ diagnostics: wave_projection(var) on any grid
+struct ProjExplicit {     // caller-supplied arrays of lprop.wave_projection (:92-94)
+    const double *dens, *lo, *up, *kk, *ll, *mlo, *mup, *dkk, *dll, *dmm, *fray;
+};
+struct ProjArgs {
+    long long n;
+    int nG;               // points of G; output has nG-1 levels
+    int tiles_per_block;
+    int var;
+    double bvf2, f_uni, dz;
+    RayPtrs r;            // resident rays   (EXPL = false)
+    ProjExplicit e;       // explicit arrays (EXPL = true)
+    const double *G;
+    double *partial;      // [blocks][NP][nG-1]
+    int *ranges;
+};
+
+template <int NP, bool FVEC, bool EXPL>
+__global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
+{
+    extern __shared__ double lds[];
+    const int nG = a.nG, ncp = nG - 1;
+    double *s_G = lds;
+    double *s_rows = s_G + nG;
+    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * NP * ncp);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < nG; i += BLOCK) s_G[i] = a.G[i];
+    for (int i = tid; i < WAVES * NP * ncp; i += BLOCK) s_rows[i] = 0.0;
+    __syncthreads();
+    int wmin = INT_MAX, wmax = INT_MIN;
+    const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
+    for (int t = 0; t < a.tiles_per_block; ++t) {
+        const long long base = (tile0 + t) * (long long)TILE;
+        if (base >= a.n) break;
+        const long long i0 = base + 2 * tid;
+        const bool v0 = i0 < a.n, v1 = i0 + 1 < a.n;
+        const bool valid[2] = {v0, v1};
+        double kk[2], ll[2], dens[2], vol[2], ff[2], lo[2], up[2], mmid[2];
+        if (EXPL) {
+            double mlo[2], mup[2], dkk[2], dll[2], dmm[2];
+            load2(a.e.dens, i0, v0, v1, dens, 0.0);
+            load2(a.e.lo, i0, v0, v1, lo, 0.0);
+            load2(a.e.up, i0, v0, v1, up, 0.0);
+            load2(a.e.kk, i0, v0, v1, kk, 1.0);
+            load2(a.e.ll, i0, v0, v1, ll, 0.0);
+            load2(a.e.mlo, i0, v0, v1, mlo, 1.0);
+            load2(a.e.mup, i0, v0, v1, mup, 1.0);
+            load2(a.e.dkk, i0, v0, v1, dkk, 0.0);
+            load2(a.e.dll, i0, v0, v1, dll, 0.0);
+            load2(a.e.dmm, i0, v0, v1, dmm, 0.0);
+            load2(a.e.fray, i0, v0, v1, ff, 0.0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                vol[r] = fabs(dkk[r] * dll[r] * dmm[r]);              // :137
+                mmid[r] = .5 * (mlo[r] + mup[r]);                     // :141
+            }
+        } else {
+            double rr[2], mm[2], drr[2], dmm[2];
+            load2(a.r.rr, i0, v0, v1, rr, 0.0);
+            load2(a.r.mm, i0, v0, v1, mm, 1.0);
+            load2(a.r.kk, i0, v0, v1, kk, 1.0);
+            load2(a.r.ll, i0, v0, v1, ll, 0.0);
+            load2(a.r.dens, i0, v0, v1, dens, 0.0);
+            load2(a.r.drr, i0, v0, v1, drr, 1.0);
+            load2(a.r.dmm, i0, v0, v1, dmm, 0.0);
+            load2(a.r.vol, i0, v0, v1, vol, 0.0);
+            if (FVEC) load2(a.r.fray, i0, v0, v1, ff, 0.0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                lo[r] = rr[r] - .5 * drr[r];                          // :655 / raytracer.py:200-201
+                up[r] = rr[r] + .5 * drr[r];
+                mmid[r] = .5 * ((mm[r] - .5 * dmm[r]) + (mm[r] + .5 * dmm[r]));   // :141, :656
+            }
+        }
+        double pay[NP][2];
+        int nlo[2], nup[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            deposit_indices<NP>(lo[r], up[r], valid[r], a.dz, nG - 2, nlo[r], nup[r]);
+            const double f = (FVEC || EXPL) ? ff[r] : a.f_uni;
+            double kh2, m2, vk2, om, cgr;
+            dispersion(kk[r], ll[r], mmid[r], f * f, a.bvf2, kh2, m2, vk2, om, cgr);
+            if (NP == 2) { pay[0][r] = cgr * kk[r] * dens[r]; pay[NP - 1][r] = cgr * ll[r] * dens[r]; }   // :148-149
+            else pay[0][r] = (a.var == 1) ? cgr * dens[r] : dens[r];                     // :167, :184
+        }
+        deposit_tile<NP>(lo, up, nlo, nup, vol, pay, s_G, a.dz, s_rows + wave * NP * ncp, ncp, lane,
+                         wmin, wmax);
+    }
+    flush_rows<NP>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
+}
+
+// ------------------------------------------------------------------ lprop.saturation on caller arrays (:561-615)
+struct SatArgs {
+    long long n;
+    int nc, direct;
+    double dt, bvf2, f0sq, sat_c, gs0, inv_dzs;
+    const double *dens, *rr, *rr_st, *drr, *drr_st, *kk, *ll, *mm, *mm_st, *dkk, *dll, *area;
+    const double *grids, *rhobar, *slrho;
+    double *out;
+};
+__global__ void __launch_bounds__(BLOCK) k_saturation(const SatArgs a)
+{
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.n) return;
+    const double rr_f = a.rr[i] + a.rr_st[i] * a.dt;                 // :591
+    const double drr_f = a.drr[i] + a.drr_st[i] * a.dt;              // :592
+    const double mm_f = a.mm[i] + a.mm_st[i] * a.dt;                 // :593
+    const double dmm_f = a.area[i] / drr_f;                          // :594
+    int md;
+    const int j = interp_locate(rr_f, a.grids, a.nc, a.gs0, a.inv_dzs, md);
+    const double rho_f = interp_eval(rr_f, j, md, a.grids, a.rhobar, a.slrho);   // :595
+    const double kh2 = a.kk[i] * a.kk[i] + a.ll[i] * a.ll[i];
+    const double m2 = a.mm[i] * a.mm[i];
+    const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m2) / (kh2 + m2));          // :597
+    const double pv = a.dkk[i] * a.dll[i] * dmm_f;                   // :599
+    const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);      // :601
+    const double d = a.dens[i];
+    const bool hit = maxd < d * pv;                                  // :604
+    if (a.direct) a.out[i] = hit ? maxd : d;                         // :606-610
+    else a.out[i] = hit ? (maxd - d) / a.dt : 0.0;                   // :612-615
+}
+
+// ------------------------------------------------------------------ upload helper
+// vol = |dkk*dll*dmm| (:137) and pvf = dkk*dll*(rr_mm_area/drr) (:594, :599 with
+// drr_final = drr + 0*dt) once per upload.
+__global__ void k_prepare(long long n, const double *dkk, const double *dll, const double *area,
+                          const double *drr, const double *dmm, double *vol, double *pvf)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double dkdl = dkk[i] * dll[i];
+    vol[i] = fabs(dkdl * dmm[i]);
+    pvf[i] = dkdl * (area[i] / drr[i]);
+}
+
+}   // namespace msgw

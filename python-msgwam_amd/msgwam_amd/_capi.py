@@ -1,0 +1,212 @@
+"""
+ctypes binding of the C ABI declared in include/msgwam_hip.h (the in-tree
+gfx950 shared library libmsgwam_hip.so) and a thin object wrapper.
+
+There is NO CPU fallback: if the library is missing or no MI355X is visible,
+everything here raises.  Build with `python __graft_entry__.py` or
+`make -C python-msgwam_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmsgwam_hip.so")
+ROT_EARTH = 7.2921e-5          # lib/libprop.py:4
+
+FIXED_BACKGROUND = 1
+DIRECT_SAT_QUIRK = 2
+DIRECT_SAT = 4
+NO_GRAPH = 8
+TIME_KERNELS = 16
+
+EXPORTS = [
+    "msgw_abi_version", "msgw_last_error", "msgw_create", "msgw_destroy", "msgw_set_config",
+    "msgw_set_column", "msgw_upload_rays", "msgw_step", "msgw_rhs", "msgw_project",
+    "msgw_project_arrays", "msgw_saturation", "msgw_download_rays", "msgw_download_column",
+    "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters",
+]
+
+_dp = C.POINTER(C.c_double)
+
+
+class Counters(C.Structure):
+    _fields_ = [("last_step_ms", C.c_double), ("ray_kernel_ms_sum", C.c_double),
+                ("ray_kernel_launches", C.c_int64), ("ray_steps_total", C.c_int64),
+                ("nray", C.c_int64), ("ngrid", C.c_int32), ("blocks", C.c_int32),
+                ("graph_steps", C.c_int32), ("nranks", C.c_int32)]
+
+
+class MsgwError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsgwError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                        "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.msgw_last_error.restype = C.c_char_p
+    lib.msgw_last_error.argtypes = [C.c_void_p]
+    lib.msgw_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int]
+    lib.msgw_destroy.argtypes = [C.c_void_p]
+    lib.msgw_set_config.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+    lib.msgw_set_column.argtypes = [C.c_void_p] + [_dp] * 6
+    lib.msgw_upload_rays.argtypes = [C.c_void_p, C.c_int64] + [_dp] * 11
+    lib.msgw_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_uint]
+    lib.msgw_rhs.argtypes = [C.c_void_p, C.c_double, C.c_uint] + [_dp] * 6
+    lib.msgw_project.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp]
+    lib.msgw_project_arrays.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_double] + [_dp] * 11 + [_dp, C.c_int, _dp]
+    lib.msgw_saturation.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_int] + [_dp] * 12 + [_dp]
+    lib.msgw_download_rays.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp]
+    lib.msgw_download_column.argtypes = [C.c_void_p, _dp, _dp]
+    lib.msgw_sync.argtypes = [C.c_void_p]
+    lib.msgw_comm_unique_id.argtypes = [C.c_void_p]
+    lib.msgw_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.msgw_set_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.msgw_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+    if lib.msgw_abi_version() != 1:
+        raise MsgwError("libmsgwam_hip.so has an unexpected ABI version")
+    _lib = lib
+    return lib
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def coriolis(phi):
+    """f = 2*Omega*sin(phi) exactly as the reference evaluates it (lib/libprop.py:382)."""
+    return 2 * ROT_EARTH * np.sin(phi)
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    lib = load_library()
+    rc = lib.msgw_comm_unique_id(buf)
+    if rc:
+        raise MsgwError(f"msgw_comm_unique_id: {lib.msgw_last_error(None).decode()}")
+    return buf.raw
+
+
+class Propagator:
+    """One GPU context: the ray state and the column live in HBM between calls."""
+
+    def __init__(self, ngrid, nray_cap, device=0):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        self.ngrid, self.cap, self.n = int(ngrid), int(nray_cap), 0
+        rc = self.lib.msgw_create(C.byref(self.ctx), int(device), self.cap, self.ngrid)
+        if rc:
+            raise MsgwError(f"msgw_create: {self.lib.msgw_last_error(None).decode()} (rc={rc})")
+
+    def _chk(self, rc, what):
+        if rc:
+            raise MsgwError(f"{what}: {self.lib.msgw_last_error(self.ctx).decode()} (rc={rc})")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.msgw_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration -------------------------------------------------------
+    def set_config(self, bvf, phi0, kappa, saturate_online, hprop=False):
+        self._chk(self.lib.msgw_set_config(self.ctx, float(bvf), float(coriolis(phi0)), float(kappa),
+                                           int(bool(saturate_online)), int(bool(hprop))), "msgw_set_config")
+
+    def set_column(self, grid, grids, rhobar, pressure_gradient, uu, vv):
+        a = [_c(x) for x in (grid, grids, rhobar, pressure_gradient, uu, vv)]
+        nc = self.ngrid - 1
+        if a[0].shape != (self.ngrid,) or a[1].shape != (nc,) or a[2].shape != (nc,) \
+                or a[3].shape != (2, nc) or a[4].shape != (nc,) or a[5].shape != (nc,):
+            raise ValueError("column arrays do not match ngrid")
+        self._chk(self.lib.msgw_set_column(self.ctx, *[_p(x) for x in a]), "msgw_set_column")
+
+    def upload_rays(self, dens, rr, drr, kk, ll, mm, dmm, phi, dkk, dll, rr_mm_area):
+        n = len(dens)
+        fray = np.broadcast_to(_c(coriolis(np.asarray(phi, dtype=np.float64))), (n,))
+        a = [_c(np.broadcast_to(x, (n,))) for x in (dens, rr, drr, kk, ll, mm, dmm, fray, dkk, dll, rr_mm_area)]
+        self._chk(self.lib.msgw_upload_rays(self.ctx, n, *[_p(x) for x in a]), "msgw_upload_rays")
+        self.n = n
+
+    def set_tuning(self, blocks_per_cu=4, graph_steps=0):
+        self._chk(self.lib.msgw_set_tuning(self.ctx, int(blocks_per_cu), int(graph_steps)), "msgw_set_tuning")
+
+    # -- hot path --------------------------------------------------------------
+    def step(self, dt, nsteps=1, flags=0):
+        self._chk(self.lib.msgw_step(self.ctx, float(dt), int(nsteps), int(flags)), "msgw_step")
+
+    def rhs(self, dt, flags=0):
+        n, nc = self.n, self.ngrid - 1
+        out = dict(dens=np.empty(n), rr=np.empty(n), mm=np.empty(n), uu=np.empty(nc), vv=np.empty(nc),
+                   pm_flux=np.empty((2, self.ngrid)))
+        self._chk(self.lib.msgw_rhs(self.ctx, float(dt), int(flags), _p(out["dens"]), _p(out["rr"]),
+                                    _p(out["mm"]), _p(out["uu"]), _p(out["vv"]), _p(out["pm_flux"])), "msgw_rhs")
+        return out
+
+    def project(self, var, G):
+        G = _c(G)
+        out = np.empty((2, len(G) - 1)) if var == 0 else np.empty(len(G) - 1)
+        self._chk(self.lib.msgw_project(self.ctx, int(var), _p(G), len(G), _p(out)), "msgw_project")
+        return out
+
+    def project_arrays(self, var, bvf, dens, phi, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, G):
+        n = len(dens)
+        fray = coriolis(np.asarray(phi, dtype=np.float64))
+        a = [_c(np.broadcast_to(x, (n,))) for x in (dens, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, fray)]
+        G = _c(G)
+        out = np.empty((2, len(G) - 1)) if var == 0 else np.empty(len(G) - 1)
+        self._chk(self.lib.msgw_project_arrays(self.ctx, n, int(var), float(bvf), *[_p(x) for x in a],
+                                               _p(G), len(G), _p(out)), "msgw_project_arrays")
+        return out
+
+    def saturation(self, dt, direct, dens, rr_center, rr_center_st, drr, drr_st, kk, ll, mm_center,
+                   mm_center_st, dkk, dll, rr_mm_area):
+        n = len(dens)
+        a = [_c(np.broadcast_to(x, (n,))) for x in (dens, rr_center, rr_center_st, drr, drr_st, kk, ll,
+                                                    mm_center, mm_center_st, dkk, dll, rr_mm_area)]
+        out = np.empty(n)
+        self._chk(self.lib.msgw_saturation(self.ctx, n, float(dt), int(bool(direct)), *[_p(x) for x in a],
+                                           _p(out)), "msgw_saturation")
+        return out
+
+    def download_rays(self):
+        dens, rr, mm = np.empty(self.n), np.empty(self.n), np.empty(self.n)
+        self._chk(self.lib.msgw_download_rays(self.ctx, self.n, _p(dens), _p(rr), _p(mm)), "msgw_download_rays")
+        return dens, rr, mm
+
+    def download_column(self):
+        nc = self.ngrid - 1
+        uu, vv = np.empty(nc), np.empty(nc)
+        self._chk(self.lib.msgw_download_column(self.ctx, _p(uu), _p(vv)), "msgw_download_column")
+        return uu, vv
+
+    def sync(self):
+        self._chk(self.lib.msgw_sync(self.ctx), "msgw_sync")
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self.lib.msgw_comm_init(self.ctx, buf, int(rank), int(nranks)), "msgw_comm_init")
+
+    def counters(self):
+        c = Counters()
+        self._chk(self.lib.msgw_counters(self.ctx, C.byref(c)), "msgw_counters")
+        return {k: getattr(c, k) for k, _ in Counters._fields_}

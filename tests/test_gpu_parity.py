@@ -1,0 +1,258 @@
+"""-m gpu: the HIP path (through the C ABI) against (1) golden vectors from the
+real reference, (2) the CPU oracles on seeded inputs, (3) size-independent
+properties at BASELINE sizes.
+
+Tolerances (fp64; north_star: per-ray state within rtol 1e-10):
+  * single RHS / single step, per ray: rtol 1e-12  
+  * flux profile / mean-flow tendencies: |err| <= 1e-12 * max|profile| (reduction order differs)
+  * multi-step well-posed horizons: rtol 1e-10     (P2/P3)
+"""
+import numpy as np
+import pytest
+
+from oracle import msgwam_oracle as orc
+from oracle.c_oracle import COracle
+from helpers import STATE_KEYS, load, setup_from, state_from, relerr
+from gpu_helpers import make_prop, gpu_state
+from msgwam_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+EVOLVING = ("dens", "rr", "mm", "uu", "vv")
+
+
+def prof_err(a, b):
+    s = np.max(np.abs(b))
+    return float(np.max(np.abs(a - b)) / (s if s > 0 else 1.0))
+
+
+@pytest.mark.parametrize("name", ["g1_rhs_f0_sat0", "g1_rhs_f0_sat1", "g1_rhs_f45_sat0", "g1_rhs_f45_sat1"])
+def test_single_rhs_vs_reference_golden(name):
+    d = load(name)
+    p = make_prop(setup_from(d), state_from(d, "in"))
+    out = p.rhs(float(d["dt"]))
+    for k in ("dens", "rr", "mm"):
+        assert relerr(out[k], d[f"out_{k}"]) <= 1e-12, k
+    assert prof_err(out["pm_flux"][:, 1:-1], d["pm_flux_inner"]) <= 1e-12
+    for k in ("uu", "vv"):
+        assert prof_err(out[k], d[f"out_{k}"]) <= 1e-12, k
+    p.close()
+
+
+@pytest.mark.parametrize("name,marks,flags,tol", [
+    ("g3_rk3_coupled_driver", (1, 10, 100), 0, 1e-10),
+    ("g3_rk3_coupled_f45", (1, 10, 100), 0, 1e-10),
+    ("g3_rk3_fixedbg_config1", (1, 10, 100, 1000), _capi.FIXED_BACKGROUND, 1e-10),
+    ("g4_saturation_online", (1, 5, 20, 60), 0, 1e-10),
+    ("g5_spectrum_coupled", (1, 3), 0, 1e-10),
+])
+def test_rk3_vs_reference_golden(name, marks, flags, tol):
+    d = load(name)
+    st = state_from(d, "in")
+    p = make_prop(setup_from(d), st)
+    done = 0
+    for n in marks:
+        p.step(float(d["dt"]), n - done, flags)
+        done = n
+        got = gpu_state(p, st)
+        for k, a in zip(STATE_KEYS, got):
+            if k in EVOLVING:
+                assert relerr(a, d[f"s{n}_{k}"]) <= tol, (name, n, k, relerr(a, d[f"s{n}_{k}"]))
+    p.close()
+
+
+def test_driver_loop_direct_saturation_quirk():
+    """raytracer.py:157-188: 1440 steps, post-step saturation with the `/1` quirk."""
+    d = load("g4_saturation_direct_driver")
+    st = state_from(d, "in")
+    p = make_prop(setup_from(d), st)
+    done = 0
+    for n in (1, 10, 100, 709, 710, 711, 1000):
+        p.step(float(d["dt"]), n - done, _capi.DIRECT_SAT_QUIRK)
+        done = n
+        got = gpu_state(p, st)
+        for k, a in zip(STATE_KEYS, got):
+            if k in EVOLVING:
+                assert relerr(a, d[f"s{n}_{k}"]) <= 1e-10, (n, k, relerr(a, d[f"s{n}_{k}"]))
+    # the first saturation event is at step 710
+    assert np.array_equal(d["s709_dens"], d["in_dens"]) and not np.array_equal(d["s710_dens"], d["in_dens"])
+    p.close()
+
+
+def _random_case(n, seed, sat, phi_mode="uniform", sorted_z=False):
+    rng = np.random.default_rng(seed)
+    grid = np.linspace(0, 100e3, 101)
+    area = rng.uniform(1e-3, 1e-1, n)
+    s = orc.Setup(grid, phi0=0.4, kappa=0.95, saturate_online=sat,
+                  dkk=np.full(n, 1e-4), dll=np.full(n, 1e-4), rr_mm_area=area)
+    uu = orc.velocities_sine_homogeneous(s.grids, 4.0, 40e3, 10e3)
+    vv = 0.3 * uu[::-1].copy()
+    s.set_pressure_gradient(uu, vv)
+    rr = rng.uniform(-1e3, 105e3, n)
+    if sorted_z:
+        rr = np.sort(rr)
+    drr = rng.uniform(50, 4000, n)
+    kk, ll = rng.normal(0, 1e-4, n), rng.normal(0, 1e-4, n)
+    mm = rng.normal(0, 2e-3, n)
+    phi = np.full(n, 0.4) if phi_mode == "uniform" else rng.uniform(-1.2, 1.2, n)
+    st = [rng.uniform(0, 1e9, n), np.zeros(n), phi, rr, drr, kk, ll, mm, area / drr, uu, vv]
+    return s, st
+
+
+@pytest.mark.parametrize("n,seed,sat,phi_mode,sorted_z", [
+    (1, 1, False, "uniform", False), (2, 2, True, "uniform", False), (513, 3, False, "vector", False),
+    (4097, 4, True, "vector", True), (100_000, 5, False, "uniform", False), (100_001, 6, True, "uniform", True),
+])
+def test_step_vs_c_oracle_random(n, seed, sat, phi_mode, sorted_z):
+    """Ragged sizes, unsorted rays (LDS-atomic deposit path) and sorted rays (DPP path),
+    per-ray latitude, online saturation; 2 coupled steps against the C oracle."""
+    s, st = _random_case(n, seed, sat, phi_mode, sorted_z)
+    want = COracle(s).step(60.0, 2, st)
+    p = make_prop(s, st)
+    p.step(60.0, 2)
+    got = gpu_state(p, st)
+    for k, a, b in zip(STATE_KEYS, got, want):
+        if k in ("uu", "vv"):
+            assert prof_err(a, b) <= 1e-11, (k, prof_err(a, b))
+        elif k in EVOLVING:
+            assert relerr(a, b) <= 1e-10, (k, relerr(a, b))
+    p.close()
+
+
+def test_fixed_background_and_direct_sat_vs_c_oracle():
+    s, st = _random_case(50_001, 11, False, "vector", False)
+    want = COracle(s, fixed_background=True).step(60.0, 3, st, direct_sat=2)
+    p = make_prop(s, st)
+    p.step(60.0, 3, _capi.FIXED_BACKGROUND | _capi.DIRECT_SAT)
+    got = gpu_state(p, st)
+    for k, a, b in zip(STATE_KEYS, got, want):
+        if k in EVOLVING:
+            assert relerr(a, b) <= 1e-11, (k, relerr(a, b))
+    assert np.array_equal(got[9], st[9])            # the column is frozen
+    p.close()
+
+
+def test_edge_rays_outside_domain_and_nan():
+    s, st = _random_case(300, 12, False)
+    st[3][:100] = -5e4            # wholly below the ground: no deposit
+    st[3][100:200] = 5e5          # far above the top
+    st[3][250] = np.nan           # NaN propagates for that ray only
+    want = COracle(s).step(60.0, 1, st)
+    p = make_prop(s, st)
+    p.step(60.0, 1)
+    got = gpu_state(p, st)
+    for k, a, b in zip(STATE_KEYS, got, want):
+        if k in ("rr", "mm"):
+            assert np.array_equal(np.isnan(a), np.isnan(b)), k
+            m = ~np.isnan(b)
+            assert relerr(a[m], b[m]) <= 1e-12, k
+        elif k in ("uu", "vv"):
+            assert prof_err(a, b) <= 1e-11, k
+    p.close()
+
+
+def test_projection_vs_reference_golden():
+    d = load("g2_projection")
+    g101 = d["grid101"]
+    grids = .5 * (g101[:-1] + g101[1:])
+    r = {k: d["rand_" + k] for k in STATE_KEYS[:9] + ["dkk", "dll", "area"]}
+    s = orc.Setup(g101, dkk=r["dkk"], dll=r["dll"], rr_mm_area=r["area"])
+    uu = np.zeros(100)
+    st = [r[k] for k in STATE_KEYS[:9]] + [uu, uu]
+    p = make_prop(s, st)
+    for gname, G in (("grid", g101), ("grids", grids)):
+        for var in (0, 1, 2):
+            want = d[f"rand_{gname}_var{var}"]
+            got_res = p.project(var, G)
+            got_arr = p.project_arrays(var, 0.01, r["dens"], r["phi"], r["rr"] - .5 * r["drr"],
+                                       r["rr"] + .5 * r["drr"], r["kk"], r["ll"], r["mm"] - .5 * r["dmm"],
+                                       r["mm"] + .5 * r["dmm"], r["dkk"], r["dll"], r["dmm"], G)
+            assert prof_err(got_res, want) <= 1e-12, (gname, var)
+            assert prof_err(got_arr, want) <= 1e-12, (gname, var)
+    # edge-case table, one ray at a time: weights must match exactly (var = 2 payload is dens = 1)
+    e = d["edges"]
+    one = np.ones(1)
+    for gname, G in (("G10", d["G10"]), ("grid", d["grid11"]), ("grids", d["grids11"])):
+        for i in range(len(e)):
+            got = p.project_arrays(2, 0.01, one, 0 * one, e[i:i + 1, 0], e[i:i + 1, 1], 2e-4 * one, 1e-4 * one,
+                                   -1e-3 * one, -1e-3 * one, one, one, one, G)
+            np.testing.assert_array_equal(got, d[f"edgerows_{gname}_var2"][i], err_msg=f"{gname} ray {i}")
+    p.close()
+
+
+def test_saturation_arrays_vs_oracle():
+    s, st = _random_case(10_000, 21, True)
+    dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = st
+    rng = np.random.default_rng(5)
+    rr_st, mm_st, drr_st = rng.normal(0, 5, len(rr)), rng.normal(0, 1e-6, len(rr)), rng.normal(0, 0.1, len(rr))
+    # scale dens so that roughly half of the rays trigger
+    cap = orc.saturation(s, 60.0, np.zeros_like(dens), rr, rr_st, drr, drr_st, kk, ll, mm, mm_st, direct=False)
+    p = make_prop(s, st)
+    for direct in (False, True):
+        want = orc.saturation(s, 60.0, dens, rr, rr_st, drr, drr_st, kk, ll, mm, mm_st, direct=direct)
+        got = p.saturation(60.0, direct, dens, rr, rr_st, drr, drr_st, kk, ll, mm, mm_st,
+                           s.dkk, s.dll, s.rr_mm_area)
+        assert relerr(got, want) <= 1e-12
+        assert 0 < np.count_nonzero(got != (dens if direct else 0.0)) < len(dens)
+    p.close()
+
+
+def test_bitwise_reproducible_and_graph_equals_eager():
+    s, st = _random_case(200_000, 31, False, "uniform", True)
+    outs = []
+    for graph_steps, flags in ((0, 0), (0, 0), (4, 0)):
+        p = make_prop(s, st)
+        p.set_tuning(4, graph_steps)
+        p.step(60.0, 9, flags)
+        outs.append(gpu_state(p, st))
+        if graph_steps:
+            assert p.counters()["graph_steps"] == graph_steps
+        p.close()
+    for k, a, b, c in zip(STATE_KEYS, *outs):
+        assert np.array_equal(a, b, equal_nan=True), f"run-to-run difference in {k}"
+        assert np.array_equal(a, c, equal_nan=True), f"graph replay differs from eager in {k}"
+
+
+def test_result_independent_of_workgroup_geometry():
+    """Different blocks-per-CU change the reduction tree; results stay within reduction noise."""
+    s, st = _random_case(150_000, 32, False, "uniform", True)
+    ref = None
+    for bpc in (1, 4, 8):
+        p = make_prop(s, st)
+        p.set_tuning(bpc, 0)
+        p.step(60.0, 2)
+        got = gpu_state(p, st)
+        p.close()
+        if ref is None:
+            ref = got
+            continue
+        for k, a, b in zip(STATE_KEYS, got, ref):
+            if k in ("rr", "mm"):
+                assert relerr(a, b) <= 1e-12, k
+
+
+def test_full_size_config3_properties_and_subsample():
+    """BASELINE config 3 size (1e6 rays, coupled): strided subsample against the C oracle run on
+    the full set for 2 steps, plus invariants (dens, frozen slots untouched; drr*dmm constant)."""
+    from msgwam_amd.spectrum import gaussian_spectrum
+    n = 1_000_000
+    grid = np.linspace(0, 100e3, 101)
+    s0 = orc.Setup(grid)
+    sp = gaussian_spectrum(n, s0.grids, s0.rhobar, alpha=0.01)
+    s = orc.Setup(grid, dkk=sp["dkk"], dll=sp["dll"], rr_mm_area=sp["area"])
+    uu = orc.velocities_sine_homogeneous(s.grids, 4.0, 40e3, 10e3)
+    vv = np.zeros_like(uu)
+    s.set_pressure_gradient(uu, vv)
+    st = [sp[k] for k in STATE_KEYS[:9]] + [uu, vv]
+    want = COracle(s).step(120.0, 2, st)
+    p = make_prop(s, st)
+    p.step(120.0, 2)
+    got = gpu_state(p, st)
+    assert np.array_equal(got[0], st[0])                       # dens constant without saturation
+    for k, a, b in zip(STATE_KEYS, got, want):
+        if k in ("rr", "mm"):
+            assert relerr(a[::97], b[::97]) <= 1e-10, k
+            assert relerr(a, b) <= 1e-10, k
+        if k in ("uu", "vv"):
+            assert prof_err(a, b) <= 1e-11, (k, prof_err(a, b))
+    p.close()
