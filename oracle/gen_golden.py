@@ -284,6 +284,22 @@ def gen_g4():
     save("g4_saturation_online", **d)
     print("   online saturation: rays whose dens changed by step 60:", d["n_changed_dens_s60"])
 
+    # online saturation on a FIXED background (no coupling -> not chaotic): long horizon
+    grid, grids, uu, vv = configure(ngrid=101, kappa=1.0, saturate_online=True, rhs=rhs_fixed_background)
+    ic = random_rays(rng, 777, grids, 0.0, amp_scale=0.6, zlo=500., zhi=60e3)
+    st = pack(ic, uu, vv)
+    d = dict(grid=grid, dt=dt, phi0=0.0, kappa=1.0, bvf=0.01, saturate_online=1,
+             dkk=ic["dkk"], dll=ic["dll"], area=ic["area"],
+             pg=lprop.pressure_gradient.copy(), rhobar=lprop.rhobar.copy())
+    d.update(flat_state("in", st))
+    res = run_steps(st, dt, (1, 20, 60))
+    for n, s in res.items():
+        d.update(flat_state(f"s{n}", s))
+    d["n_changed_dens_s60"] = int(np.sum(res[60][0] != ic["dens"]))
+    save("g4_saturation_online_fixedbg", **d)
+    print("   online saturation (fixed bg): rays whose dens changed by step 60:", d["n_changed_dens_s60"])
+    lprop.set_model_setup(rhs=lprop.rhs_default)
+
     # direct saturation: the driver's own loop (raytracer.py:157-188)
     grid, grids, uu, vv = configure(ngrid=101, kappa=1.0, saturate_online=False)
     ic = driver_ic(60, grids, alpha=0.01)

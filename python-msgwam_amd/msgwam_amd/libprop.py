@@ -1,0 +1,315 @@
+"""
+Drop-in mirror of the module surface of python-msgwam's `lib/libprop.py` for the
+ray-propagation hot path, backed by the MI355X HIP library (through
+`_capi`, a ctypes binding of include/msgwam_hip.h).
+
+    import msgwam_amd.libprop as lprop      # instead of `import lib.libprop as lprop`
+
+Same names, argument orders and return shapes as the reference for everything
+`raytracer.py` touches: the module attributes `HPROP_GLOBAL`,
+`grid`, `grids`, `rhobar`, `pressure_gradient`, `model_config`, `statics`; the
+setters; `omega`; and the hot-path entry points `RK3`, `rhs_default`,
+`saturation`, `wave_projection`, which run on the GPU.  There is NO CPU
+fallback for those four: without the HIP library or a GPU they raise.
+
+Scope and deliberate differences (also in DESIGN.md):
+  * Only the `HPROP_GLOBAL = False` branch (the driver's, raytracer.py:38) with
+    scalar `bvf` is implemented; `HPROP_GLOBAL = True` raises NotImplementedError
+    at the first hot-path call.
+  * `model_config['rhs']` must be one of this module's built-ins (`rhs_default`,
+    `rhs_fixed_background`).  An arbitrary Python callable is opaque host code
+    that cannot run on the device; it raises TypeError instead of silently
+    running a CPU path.
+  * `RK3` builds its 11-slot object array slot by slot, so `nray == ngrid-1`
+    works (the reference crashes there, lib/libprop.py:668-674).
+  * `wave_projection` supports var 0, 1, 2 (var 3, 4 have no caller).
+Column/initial-condition helpers (`set_hydrostatics`, `set_pressure_gradient`,
+`velocities_*`, `omega`) are one-off O(ngrid)/O(nray) host-side setup in numpy,
+as in the reference.
+"""
+import numpy as np
+
+from . import _capi
+
+RAD_EARTH = 6378e3          # lib/libprop.py:3
+ROT_EARTH = 7.2921e-5       # lib/libprop.py:4
+HPROP_GLOBAL = True         # lib/libprop.py:5 (the driver switches it off, raytracer.py:38)
+pressure_gradient = 0       # lib/libprop.py:6
+grid = None                 # lib/libprop.py:7
+grids = None                # lib/libprop.py:8
+rhobar = 1                  # lib/libprop.py:9
+model_config = {}           # lib/libprop.py:10
+statics = {}                # lib/libprop.py:11
+
+
+# ----------------------------------------------------------------------------
+# configuration surface (lib/libprop.py:14-89)
+# ----------------------------------------------------------------------------
+def set_statics(**kwargs):
+    """lib/libprop.py:14-27"""
+    statics.update(kwargs)
+
+
+def set_model_setup(**kwargs):
+    """lib/libprop.py:30-44"""
+    model_config.update(kwargs)
+
+
+def get_model_setup():
+    """lib/libprop.py:85-89"""
+    return model_config
+
+
+def set_hydrostatics():
+    """lib/libprop.py:47-62: hydrostatic density on the staggered grid."""
+    global rhobar
+    if model_config['boussinesq']:
+        rhobar = model_config['rhobar0'] * np.ones(grids.shape)
+    else:
+        rhobar = model_config['rhobar0'] * np.exp(-grids / model_config['hh'])
+
+
+def set_pressure_gradient(uu, vv):
+    """lib/libprop.py:65-82: geostrophically balanced pressure gradient."""
+    global pressure_gradient
+    ff = 2 * ROT_EARTH * np.sin(model_config['phi0'])
+    pg = np.empty((2, len(grids)))
+    pg[0] = rhobar * ff * vv
+    pg[1] = - rhobar * ff * uu
+    pressure_gradient = pg
+
+
+def velocities_tanh_homogeneous(rr):
+    """lib/libprop.py:253-273"""
+    shape = (np.tanh((rr - model_config['rr0']) / model_config['sig_rr']) + 1) * 0.5
+    return model_config['u0'] * shape
+
+
+def velocities_gauss_homogeneous(rr):
+    """lib/libprop.py:276-303 (its out-of-bounds mask can never be true; kept as is)."""
+    u0, rr0, sig = model_config['u0'], model_config['rr0'], model_config['sig_rr']
+    uu = u0 * np.exp(-(rr - rr0) ** 2 / 2 / sig ** 2)
+    uu[np.where((rr <= rr0 - 3 * sig) & (rr >= rr0 + 3 * sig))] = 0.
+    return uu
+
+
+def velocities_sine_homogeneous(rr):
+    """lib/libprop.py:306-325 (the driver's wind profile, raytracer.py:93)."""
+    envelope = .5 * (np.tanh((rr - model_config['rr0']) / model_config['sig_rr']) + 1)
+    return model_config['u0'] * envelope * np.sin(rr / model_config['sig_rr'] * 2 * np.pi)
+
+
+def omega(kk, ll, mm, phi):
+    """lib/libprop.py:369-383: intrinsic frequency (host-side; the driver uses it
+    for the initial wave-action density, raytracer.py:114)."""
+    bvf = model_config['bvf']
+    ff = 2 * ROT_EARTH * np.sin(phi)
+    return np.sqrt((bvf ** 2 * (kk ** 2 + ll ** 2) + ff ** 2 * mm ** 2) / (kk ** 2 + ll ** 2 + mm ** 2))
+
+
+# ----------------------------------------------------------------------------
+# device backend
+# ----------------------------------------------------------------------------
+class _Backend:
+    """One lazily created GPU context + what is resident in it."""
+
+    def __init__(self):
+        self.prop = None
+        self.device = 0
+        self.cfg = None         # (bvf, phi0, kappa, saturate_online)
+        self.col = None         # copies of grid, grids, rhobar, pressure_gradient
+        self.col_uv = None      # the (uu, vv) OBJECTS that are resident
+        self.rays = None        # dict: input objects resident + statics objects
+        self.out = None         # the arrays returned by the last RK3
+
+    def context(self, ngrid, nray):
+        p = self.prop
+        if p is None or p.ngrid != ngrid or nray > p.cap:
+            if p is not None:
+                p.close()
+            cap = max(int(nray), 1024)
+            if p is not None and p.ngrid == ngrid:
+                cap = max(cap, 2 * p.cap)
+            self.prop = _capi.Propagator(ngrid, cap, device=self.device)
+            self.cfg = self.col = self.col_uv = self.rays = self.out = None
+        return self.prop
+
+    def reset(self):
+        if self.prop is not None:
+            self.prop.close()
+        self.__init__()
+
+
+_backend = _Backend()
+
+
+def set_device(device):
+    """Select the HIP device of this process (one process per GPU)."""
+    _backend.reset()
+    _backend.device = int(device)
+
+
+def release_device():
+    """Free the GPU context (the next hot-path call recreates it)."""
+    dev = _backend.device
+    _backend.reset()
+    _backend.device = dev
+
+
+def _check_scope():
+    if HPROP_GLOBAL:
+        raise NotImplementedError(
+            "HPROP_GLOBAL=True (horizontal propagation on the sphere) is outside the scope of the "
+            "MI355X path; set lprop.HPROP_GLOBAL = False as raytracer.py:38 does")
+    if grid is None or grids is None:
+        raise RuntimeError("lprop.grid / lprop.grids are not set (raytracer.py:76-77)")
+    if np.ndim(model_config['bvf']) != 0:
+        raise NotImplementedError("only a scalar bvf is supported (as in the reference)")
+
+
+def _same(a, b):
+    return a is b or (a is not None and b is not None and np.array_equal(a, b))
+
+
+def _sync_config_and_column(p, uu, vv, force_uv):
+    cfg = (float(model_config['bvf']), float(model_config['phi0']), float(model_config['kappa']),
+           bool(model_config['saturate_online']))
+    if _backend.cfg != cfg:
+        p.set_config(cfg[0], cfg[1], cfg[2], cfg[3], hprop=False)
+        _backend.cfg = cfg
+    col = _backend.col
+    new = (np.asarray(grid, dtype=np.float64), np.asarray(grids, dtype=np.float64),
+           np.asarray(rhobar, dtype=np.float64), np.asarray(pressure_gradient, dtype=np.float64))
+    if np.shape(new[3]) != (2, len(new[1])):
+        raise RuntimeError("lprop.pressure_gradient is not set: call set_pressure_gradient(uu, vv) "
+                           "(raytracer.py:99)")
+    stale = col is None or any(not _same(a, b) for a, b in zip(col, new))
+    uv_resident = (not force_uv and not stale and _backend.col_uv is not None
+                   and _backend.col_uv[0] is uu and _backend.col_uv[1] is vv)
+    if not uv_resident:
+        p.set_column(new[0], new[1], new[2], new[3], uu, vv)
+        _backend.col = tuple(a.copy() for a in new)
+        _backend.col_uv = (uu, vv)
+
+
+_RAY_SLOTS = (0, 3, 4, 5, 6, 7, 8, 2)      # dens rr drr kk ll mm dmm phi
+
+
+def _sync_rays(p, var):
+    st = (statics['dkk'], statics['dll'], statics['rr_mm_area'])     # KeyError as in :585-587
+    res = _backend.rays
+    resident = (res is not None and all(res['in'][i] is var[i] for i in _RAY_SLOTS)
+                and all(a is b for a, b in zip(res['st'], st)))
+    if not resident:
+        dens, lam, phi, rr, drr, kk, ll, mm, dmm = [np.asarray(var[i], dtype=np.float64) for i in range(9)]
+        p.upload_rays(dens, rr, drr, kk, ll, mm, dmm, phi, st[0], st[1], st[2])
+    return not resident
+
+
+def _prepare(var):
+    _check_scope()
+    if len(var) != 11:
+        raise ValueError("the state vector must have 11 slots (lib/libprop.py:629)")
+    nray = len(var[0])
+    p = _backend.context(len(grid), nray)
+    _sync_config_and_column(p, var[9], var[10], force_uv=False)
+    _sync_rays(p, var)
+    return p
+
+
+def _pack(slots):
+    out = np.empty(len(slots), dtype=object)
+    for i, a in enumerate(slots):
+        out[i] = a
+    return out
+
+
+def _flags_for(rhs):
+    if rhs is rhs_default:
+        return 0
+    if rhs is rhs_fixed_background:
+        return _capi.FIXED_BACKGROUND
+    raise TypeError(
+        "model_config['rhs'] must be msgwam_amd.libprop.rhs_default or .rhs_fixed_background; an "
+        "arbitrary Python callable cannot run on the GPU and there is no CPU fallback")
+
+
+# ----------------------------------------------------------------------------
+# hot path (GPU)
+# ----------------------------------------------------------------------------
+def rhs_default(dt, var_in):
+    """lib/libprop.py:618-676 on the GPU: the 11 tendencies of
+    [dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv].  With HPROP off the
+    tendencies of lam, phi, drr, kk, ll, dmm are identically zero."""
+    return _rhs(dt, var_in, 0)
+
+
+def rhs_fixed_background(dt, var_in):
+    """Built-in rhs hook for a frozen mean flow (BASELINE configs 1, 2): the
+    reference expresses it as a user hook that zeroes slots 9, 10 of
+    rhs_default's result (lib/libprop.py:691)."""
+    return _rhs(dt, var_in, _capi.FIXED_BACKGROUND)
+
+
+def _rhs(dt, var_in, flags):
+    p = _prepare(var_in)
+    t = p.rhs(dt, flags)
+    _backend.rays = dict(**{'in': list(var_in)}, st=(statics['dkk'], statics['dll'], statics['rr_mm_area']))
+    _backend.col_uv = (var_in[9], var_in[10])
+    z = lambda: np.zeros(np.shape(var_in[5]))
+    return _pack([t['dens'], z(), z(), t['rr'], z(), z(), z(), t['mm'], z(), t['uu'], t['vv']])
+
+
+def RK3(dt, var):
+    """lib/libprop.py:680-700 on the GPU: one low-storage RK3 step of the full
+    state (rays AND mean flow: uu, vv advance at every stage).  The state stays
+    resident between calls when the caller passes back the arrays it was given."""
+    flags = _flags_for(model_config['rhs'])
+    p = _prepare(var)
+    p.step(dt, 1, flags | _capi.NO_GRAPH)
+    dens, rr, mm = p.download_rays()
+    uu, vv = p.download_column()
+    out = [dens, np.array(var[1], dtype=np.float64), np.array(var[2], dtype=np.float64), rr,
+           np.array(var[4], dtype=np.float64), np.array(var[5], dtype=np.float64),
+           np.array(var[6], dtype=np.float64), mm, np.array(var[8], dtype=np.float64), uu, vv]
+    # what is now on the device corresponds to `out`; frozen slots are equal by value
+    _backend.rays = dict(**{'in': list(out)}, st=(statics['dkk'], statics['dll'], statics['rr_mm_area']))
+    _backend.col_uv = (uu, vv)
+    return _pack(out)
+
+
+def saturation(dt, dens, rr_center, rr_center_st, drr, drr_st, kk, ll, mm_center, mm_center_st,
+               direct=False):
+    """lib/libprop.py:561-615 on the GPU (the driver's post-step call,
+    raytracer.py:182-188, uses direct=True)."""
+    _check_scope()
+    n = len(dens)
+    p = _backend.context(len(grid), n)
+    # the column may not be resident yet when the caller never ran RK3
+    uv = _backend.col_uv or (np.zeros(len(grids)), np.zeros(len(grids)))
+    _sync_config_and_column(p, uv[0], uv[1], force_uv=False)
+    return p.saturation(dt, direct, dens, rr_center, rr_center_st, drr, drr_st, kk, ll, mm_center,
+                        mm_center_st, statics['dkk'], statics['dll'], statics['rr_mm_area'])
+
+
+def wave_projection(dens, lam, phi, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, grid,
+                    var=0):
+    """lib/libprop.py:92-221 on the GPU for var in {0, 1, 2}."""
+    if var not in (0, 1, 2):
+        raise NotImplementedError("wave_projection var 3/4 (interface variants) have no caller in the "
+                                  "reference and are not implemented")
+    n = len(dens)
+    ng = len(globals()['grid']) if globals()['grid'] is not None else len(grid)
+    p = _backend.context(ng, n)
+    return p.project_arrays(var, model_config['bvf'], dens, phi, rr_low, rr_up, kk, ll, mm_low, mm_up,
+                            dkk, dll, dmm, grid)
+
+
+# ----------------------------------------------------------------------------
+# defaults, as at import of the reference (lib/libprop.py:703-726)
+# ----------------------------------------------------------------------------
+set_model_setup(
+    u0=80, phi0=np.deg2rad(-60), sig_phi=np.deg2rad(3), rr0=30000, rr1=40000, sig_rr=10000, drr=1,
+    bvf=0.01, rhs=rhs_default, geostrophy=True, boussinesq=False, hh=8500, rhobar0=1.2, kappa=0.95,
+    saturate_online=True)
+set_statics(int_dll=1, int_dkk=1, rr_mm_area=0)

@@ -43,7 +43,10 @@ def test_single_rhs_vs_reference_golden(name):
     ("g3_rk3_coupled_driver", (1, 10, 100), 0, 1e-10),
     ("g3_rk3_coupled_f45", (1, 10, 100), 0, 1e-10),
     ("g3_rk3_fixedbg_config1", (1, 10, 100, 1000), _capi.FIXED_BACKGROUND, 1e-10),
-    ("g4_saturation_online", (1, 5, 20, 60), 0, 1e-10),
+    # strong-amplitude coupled case: chaotic (summation-order noise grows x10 per step, also between
+    # two CPU runs that differ only in ray order), so parity is asserted on steps 1 and 5 only
+    ("g4_saturation_online", (1, 5), 0, 1e-10),
+    ("g4_saturation_online_fixedbg", (1, 20, 60), _capi.FIXED_BACKGROUND, 1e-10),
     ("g5_spectrum_coupled", (1, 3), 0, 1e-10),
 ])
 def test_rk3_vs_reference_golden(name, marks, flags, tol):

@@ -55,6 +55,7 @@ def test_c_projection(var):
     ("g3_rk3_coupled_f45", (1, 10, 100), False),
     ("g3_rk3_fixedbg_config1", (1, 10, 100, 1000), True),
     ("g4_saturation_online", (1, 5, 20, 60), False),
+    ("g4_saturation_online_fixedbg", (1, 20, 60), True),
     ("g5_spectrum_coupled", (1, 3), False),
 ])
 def test_c_rk3(name, marks, fixed):

@@ -120,6 +120,15 @@ def test_g4_saturation_online():
     assert int(d["n_changed_dens_s60"]) >= 200
 
 
+def test_g4_saturation_online_fixed_background():
+    d = load("g4_saturation_online_fixedbg")
+    got = _run(d, (1, 20, 60), fixed_background=True)
+    for n, st in got.items():
+        for k, a in zip(STATE_KEYS, st):
+            assert relerr(a, d[f"s{n}_{k}"]) <= 1e-12, (n, k)
+    assert int(d["n_changed_dens_s60"]) >= 200
+
+
 def test_g4_saturation_direct_driver_loop():
     """raytracer.py:157-188 incl. the `/1` quirk; 24 saturation events, the
     first at step 710."""
