@@ -46,7 +46,9 @@ __global__ void __launch_bounds__(COL_BLOCK) k_column(const ColArgs a)
     const int tid = threadIdx.x;
 
     if (MODE & COL_REDUCE) {
-        for (int i = tid; i < 2 * a.nblocks; i += COL_BLOCK) s_rng[i] = a.ranges[i];
+        // second-level rows (written by k_flux_reduce1) are dense: no range descriptors
+        for (int i = tid; i < 2 * a.nblocks; i += COL_BLOCK)
+            s_rng[i] = a.ranges ? a.ranges[i] : ((i & 1) ? INT_MAX : INT_MIN);
         __syncthreads();
         for (int idx = tid; idx < a.nseg * ncols; idx += COL_BLOCK) {
             const int seg = idx / ncols, col = idx - seg * ncols;
@@ -141,6 +143,59 @@ __global__ void __launch_bounds__(COL_BLOCK) k_column(const ColArgs a)
         const double dx = a.xg[j + 1] - a.xg[j];
         a.slu[j] = (s_du[j + 1] - s_du[j]) / dx;
         a.slv[j] = (s_dv[j + 1] - s_dv[j]) / dx;
+    }
+}
+
+// First level of the flux reduction when there are many workgroup rows: G1
+// workgroups each sum a contiguous slice of rows (fixed order) into one dense
+// row of `out` [G1][ncols].  Keeps the single-workgroup k_column off the
+// one-CU bandwidth limit (977 rows x 198 columns = 1.5 MB at 1e6 rays).
+struct Red1Args {
+    int nblocks, ncols, ncp, npay, nseg;
+    const double *partial;
+    const int *ranges;
+    double *out;
+};
+__global__ void __launch_bounds__(COL_BLOCK) k_flux_reduce1(const Red1Args a)
+{
+    extern __shared__ double lds[];
+    double *s_seg = lds;                                              // [nseg][ncols]
+    int *s_rng = reinterpret_cast<int *>(s_seg + (size_t)a.nseg * a.ncols);
+    const int tid = threadIdx.x;
+    const int r0 = (int)((long long)blockIdx.x * a.nblocks / gridDim.x);
+    const int r1 = (int)((long long)(blockIdx.x + 1) * a.nblocks / gridDim.x);
+    const int nr = r1 - r0;
+    for (int i = tid; i < 2 * nr; i += COL_BLOCK) s_rng[i] = a.ranges[2 * r0 + i];
+    __syncthreads();
+    for (int idx = tid; idx < a.nseg * a.ncols; idx += COL_BLOCK) {
+        const int seg = idx / a.ncols, col = idx - seg * a.ncols;
+        const int c = col % a.ncp;
+        const int b0 = (int)((long long)seg * nr / a.nseg), b1 = (int)((long long)(seg + 1) * nr / a.nseg);
+        const double *src = a.partial + (size_t)r0 * a.ncols + col;
+        double acc = 0.0;
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(b + u) * a.ncols];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = (c >= s_rng[2 * (b + u)]) && (c < s_rng[2 * (b + u) + 1]);
+                acc = acc + (in ? v[u] : 0.0);
+            }
+        }
+        for (; b < b1; ++b) {
+            const double v = src[(size_t)b * a.ncols];
+            const bool in = (c >= s_rng[2 * b]) && (c < s_rng[2 * b + 1]);
+            acc = acc + (in ? v : 0.0);
+        }
+        s_seg[idx] = acc;
+    }
+    __syncthreads();
+    for (int col = tid; col < a.ncols; col += COL_BLOCK) {
+        double tot = s_seg[col];
+        for (int s = 1; s < a.nseg; ++s) tot = tot + s_seg[s * a.ncols + col];
+        a.out[(size_t)blockIdx.x * a.ncols + col] = tot;
     }
 }
 

@@ -5,6 +5,7 @@
 #include "msgwam_hip.h"
 
 #include <dlfcn.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -97,6 +98,8 @@ struct msgw_ctx {
     size_t partial_elems = 0;
     int *ranges = nullptr;
     int ranges_cap = 0;
+    double *row2 = nullptr;          // [RED1_GROUPS][ncols] second-level flux rows
+    size_t row2_elems = 0;
 
     // graph
     int graph_steps = 0;
@@ -115,6 +118,7 @@ struct msgw_ctx {
     msgw_counters_t cnt{};
     std::vector<hipEvent_t> kev;
     size_t kev_used = 0;
+    bool time_next = false;          // attach begin/end events to the ray kernels being enqueued
 };
 
 namespace {
@@ -152,6 +156,9 @@ size_t col_lds_bytes(int ng, int nseg, int ncols, int nblocks)
     return sizeof(double) * (size_t)(2 * ng + 2 * (ng - 1) + 2 * (ng - 2) + (size_t)nseg * ncols) +
            sizeof(int) * 2 * (size_t)nblocks + 16;
 }
+constexpr int RED1_GROUPS = 64;      // first-level reduce workgroups
+constexpr int RED1_MIN_ROWS = 128;   // below this the single-workgroup column kernel reads the rows itself
+
 int pick_nseg(int ncols)
 {
     int s = COL_BLOCK / (ncols > 0 ? ncols : 1);
@@ -209,6 +216,33 @@ int ensure_partial(msgw_ctx *c, int blocks, size_t row_elems)
         HIPCHK(c, hipMemsetAsync(c->ranges, 0, sizeof(int) * 2 * (size_t)blocks, c->stream));
         c->ranges_cap = blocks;
     }
+    const size_t need2 = (size_t)RED1_GROUPS * row_elems;
+    if (need2 > c->row2_elems) {
+        drop_graph(c);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->row2) HIPCHK(c, hipFree(c->row2));
+        c->row2 = nullptr;
+        HIPCHK(c, hipMalloc(&c->row2, need2 * sizeof(double)));
+        c->row2_elems = need2;
+    }
+    return MSGW_OK;
+}
+
+// First level of the flux reduction (many workgroup rows -> RED1_GROUPS dense rows);
+// rewrites `a` so that the column kernel reads the second-level rows.
+int reduce_level1(msgw_ctx *c, ColArgs &a)
+{
+    if (a.nblocks < RED1_MIN_ROWS) return MSGW_OK;
+    Red1Args r{};
+    r.nblocks = a.nblocks; r.npay = a.npay; r.ncp = a.ncp; r.ncols = a.npay * a.ncp;
+    r.nseg = pick_nseg(r.ncols);
+    r.partial = a.partial; r.ranges = a.ranges; r.out = c->row2;
+    const int rows_per_group = (a.nblocks + RED1_GROUPS - 1) / RED1_GROUPS + 1;
+    const size_t lds = sizeof(double) * (size_t)r.nseg * r.ncols + sizeof(int) * 2 * (size_t)rows_per_group + 16;
+    if (int rc = ensure_lds(c, k_flux_reduce1, lds)) return rc;
+    hipLaunchKernelGGL(k_flux_reduce1, dim3(RED1_GROUPS), dim3(COL_BLOCK), lds, c->stream, r);
+    HIPCHK(c, hipGetLastError());
+    a.partial = c->row2; a.ranges = nullptr; a.nblocks = RED1_GROUPS;
     return MSGW_OK;
 }
 
@@ -255,16 +289,40 @@ ColArgs make_col_args(msgw_ctx *c, double dt, unsigned flags)
     return a;
 }
 
+hipEvent_t *timing_events(msgw_ctx *c)
+{
+    if (c->kev_used + 2 > c->kev.size()) {
+        const size_t old = c->kev.size();
+        c->kev.resize(old + 512);
+        for (size_t i = old; i < c->kev.size(); ++i)
+            if (hipEventCreate(&c->kev[i]) != hipSuccess) { c->kev.resize(i); return nullptr; }
+    }
+    hipEvent_t *p = &c->kev[c->kev_used];
+    c->kev_used += 2;
+    return p;
+}
+
 // ---- kernel dispatch --------------------------------------------------------
+// Ray kernels are launched through hipExtLaunchKernelGGL so that, when asked, a pair of
+// events receives the kernel's own begin/end timestamps (no launch gap in the interval).
+template <typename K>
+int launch_ray_kernel(msgw_ctx *c, K k, size_t lds, const StageArgs &a)
+{
+    if (int rc = ensure_lds(c, k, lds)) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->time_next) {
+        hipEvent_t *ev = timing_events(c);
+        if (ev) { e0 = ev[0]; e1 = ev[1]; }
+    }
+    hipExtLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, e0, e1, 0, a);
+    HIPCHK(c, hipGetLastError());
+    return MSGW_OK;
+}
+
 template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
 int launch_stage_t(msgw_ctx *c, const StageArgs &a)
 {
-    const size_t lds = stage_lds_bytes(c->ng);
-    auto k = k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT>;
-    if (int rc = ensure_lds(c, k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    return MSGW_OK;
+    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT>, stage_lds_bytes(c->ng), a);
 }
 
 // mode: 0 plain, 1 online saturation, 2 direct (driver) saturation
@@ -296,12 +354,7 @@ int launch_probe(msgw_ctx *c, const StageArgs &a, bool sat, bool deposit)
 template <bool SAT, bool FVEC, bool DIRECT>
 int launch_fixed_t(msgw_ctx *c, const StageArgs &a)
 {
-    const size_t lds = stage_lds_bytes(c->ng);
-    auto k = k_ray_step_fixed<SAT, FVEC, DIRECT>;
-    if (int rc = ensure_lds(c, k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    return MSGW_OK;
+    return launch_ray_kernel(c, k_ray_step_fixed<SAT, FVEC, DIRECT>, stage_lds_bytes(c->ng), a);
 }
 int launch_fixed(msgw_ctx *c, const StageArgs &a, int mode)
 {
@@ -334,8 +387,10 @@ int allreduce_flux(msgw_ctx *c)
 
 // flux finalise (+ all-reduce over the ranks) + mean-flow RK stage
 template <int STAGE>
-int column_stage(msgw_ctx *c, const ColArgs &a)
+int column_stage(msgw_ctx *c, const ColArgs &a0)
 {
+    ColArgs a = a0;
+    if (int rc = reduce_level1(c, a)) return rc;
     if (c->nranks > 1) {
         if (int rc = launch_column_t<STAGE, COL_REDUCE>(c, a)) return rc;
         if (int rc = allreduce_flux(c)) return rc;
@@ -344,30 +399,16 @@ int column_stage(msgw_ctx *c, const ColArgs &a)
     return launch_column_t<STAGE, COL_REDUCE | COL_UPDATE>(c, a);
 }
 
-hipEvent_t *timing_events(msgw_ctx *c)
-{
-    if (c->kev_used + 2 > c->kev.size()) {
-        const size_t old = c->kev.size();
-        c->kev.resize(old + 512);
-        for (size_t i = old; i < c->kev.size(); ++i)
-            if (hipEventCreate(&c->kev[i]) != hipSuccess) { c->kev.resize(i); return nullptr; }
-    }
-    hipEvent_t *p = &c->kev[c->kev_used];
-    c->kev_used += 2;
-    return p;
-}
-
 // Enqueue one RK3 step (lib/libprop.py:693-698) on the context's stream.
 int enqueue_step(msgw_ctx *c, double dt, unsigned flags, bool time_kernels)
 {
     const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
     const StageArgs sa = make_stage_args(c, dt, flags);
     auto timed = [&](auto &&launch) -> int {
-        hipEvent_t *ev = time_kernels ? timing_events(c) : nullptr;
-        if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
-        if (int rc = launch()) return rc;
-        if (ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
-        return MSGW_OK;
+        c->time_next = time_kernels;
+        const int rc = launch();
+        c->time_next = false;
+        return rc;
     };
     if (flags & MSGW_FIXED_BACKGROUND)
         return timed([&] { return launch_fixed(c, sa, mode); });
@@ -460,6 +501,7 @@ int msgw_destroy(msgw_ctx *c)
     if (c->colbuf) (void)hipFree(c->colbuf);
     if (c->partial) (void)hipFree(c->partial);
     if (c->ranges) (void)hipFree(c->ranges);
+    if (c->row2) (void)hipFree(c->row2);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -661,6 +703,7 @@ static int run_projection(msgw_ctx *c, ProjArgs &a, bool expl, int np, const dou
         ColArgs ca{};
         ca.ng = 4; ca.nblocks = blocks; ca.npay = np; ca.ncp = ncp; ca.nseg = pick_nseg(np * ncp);
         ca.partial = c->partial; ca.ranges = c->ranges; ca.flux = dflux;
+        if ((rc = reduce_level1(c, ca))) break;
         if ((rc = launch_column_t<4, COL_REDUCE>(c, ca))) break;
         if (hipMemcpyAsync(out, dflux, sizeof(double) * (size_t)np * ncp, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "D2H of projection failed"); break; }
         if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "sync failed in projection"); break; }

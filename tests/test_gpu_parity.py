@@ -26,6 +26,21 @@ def prof_err(a, b):
     return float(np.max(np.abs(a - b)) / (s if s > 0 else 1.0))
 
 
+def check_state(got, want, tol_ray, tol_col, what=""):
+    """Per-ray slots: element-wise relative error.  The wind columns uu, vv are the two
+    components of one vector and a component can be a pure cancellation residue (vv ~ 1e-20
+    when all rays share an azimuth pair), so their error is measured against the common
+    velocity scale max(|uu|, |vv|)."""
+    for k, a, b in zip(STATE_KEYS, got, want):
+        if k in ("dens", "rr", "mm"):
+            e = relerr(a, b)
+            assert e <= tol_ray, (what, k, e)
+    scale = max(np.max(np.abs(want[9])), np.max(np.abs(want[10])), 1e-300)
+    for k, i in (("uu", 9), ("vv", 10)):
+        e = float(np.max(np.abs(got[i] - want[i])) / scale)
+        assert e <= tol_col, (what, k, e)
+
+
 @pytest.mark.parametrize("name", ["g1_rhs_f0_sat0", "g1_rhs_f0_sat1", "g1_rhs_f45_sat0", "g1_rhs_f45_sat1"])
 def test_single_rhs_vs_reference_golden(name):
     d = load(name)
@@ -57,10 +72,7 @@ def test_rk3_vs_reference_golden(name, marks, flags, tol):
     for n in marks:
         p.step(float(d["dt"]), n - done, flags)
         done = n
-        got = gpu_state(p, st)
-        for k, a in zip(STATE_KEYS, got):
-            if k in EVOLVING:
-                assert relerr(a, d[f"s{n}_{k}"]) <= tol, (name, n, k, relerr(a, d[f"s{n}_{k}"]))
+        check_state(gpu_state(p, st), state_from(d, f"s{n}"), tol, tol, (name, n))
     p.close()
 
 
@@ -73,10 +85,7 @@ def test_driver_loop_direct_saturation_quirk():
     for n in (1, 10, 100, 709, 710, 711, 1000):
         p.step(float(d["dt"]), n - done, _capi.DIRECT_SAT_QUIRK)
         done = n
-        got = gpu_state(p, st)
-        for k, a in zip(STATE_KEYS, got):
-            if k in EVOLVING:
-                assert relerr(a, d[f"s{n}_{k}"]) <= 1e-10, (n, k, relerr(a, d[f"s{n}_{k}"]))
+        check_state(gpu_state(p, st), state_from(d, f"s{n}"), 1e-10, 1e-10, n)
     # the first saturation event is at step 710
     assert np.array_equal(d["s709_dens"], d["in_dens"]) and not np.array_equal(d["s710_dens"], d["in_dens"])
     p.close()
@@ -113,12 +122,7 @@ def test_step_vs_c_oracle_random(n, seed, sat, phi_mode, sorted_z):
     want = COracle(s).step(60.0, 2, st)
     p = make_prop(s, st)
     p.step(60.0, 2)
-    got = gpu_state(p, st)
-    for k, a, b in zip(STATE_KEYS, got, want):
-        if k in ("uu", "vv"):
-            assert prof_err(a, b) <= 1e-11, (k, prof_err(a, b))
-        elif k in EVOLVING:
-            assert relerr(a, b) <= 1e-10, (k, relerr(a, b))
+    check_state(gpu_state(p, st), want, 1e-10, 1e-11, n)
     p.close()
 
 
@@ -188,8 +192,11 @@ def test_saturation_arrays_vs_oracle():
     dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = st
     rng = np.random.default_rng(5)
     rr_st, mm_st, drr_st = rng.normal(0, 5, len(rr)), rng.normal(0, 1e-6, len(rr)), rng.normal(0, 0.1, len(rr))
-    # scale dens so that roughly half of the rays trigger
-    cap = orc.saturation(s, 60.0, np.zeros_like(dens), rr, rr_st, drr, drr_st, kk, ll, mm, mm_st, direct=False)
+    # put dens around the trigger threshold (max_dens / phase volume) so that about half the rays trigger
+    cap = orc.saturation(s, 60.0, np.full_like(dens, np.inf), rr, rr_st, drr, drr_st, kk, ll, mm, mm_st, direct=True)
+    pv = s.dkk * s.dll * (s.rr_mm_area / (drr + drr_st * 60.0))
+    dens = np.abs(cap / pv) * rng.uniform(0.5, 1.5, len(rr))
+    st[0] = dens
     p = make_prop(s, st)
     for direct in (False, True):
         want = orc.saturation(s, 60.0, dens, rr, rr_st, drr, drr_st, kk, ll, mm, mm_st, direct=direct)
@@ -252,10 +259,6 @@ def test_full_size_config3_properties_and_subsample():
     p.step(120.0, 2)
     got = gpu_state(p, st)
     assert np.array_equal(got[0], st[0])                       # dens constant without saturation
-    for k, a, b in zip(STATE_KEYS, got, want):
-        if k in ("rr", "mm"):
-            assert relerr(a[::97], b[::97]) <= 1e-10, k
-            assert relerr(a, b) <= 1e-10, k
-        if k in ("uu", "vv"):
-            assert prof_err(a, b) <= 1e-11, (k, prof_err(a, b))
+    check_state(got, want, 1e-10, 1e-11, "config3")
+    assert not np.array_equal(got[9], st[9])                   # the mean flow really moved
     p.close()
