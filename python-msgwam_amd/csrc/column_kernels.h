@@ -58,21 +58,18 @@ __global__ void __launch_bounds__(COL_BLOCK) k_column(const ColArgs a)
             const double *src = a.partial + (size_t)p * a.ncp + c;
             const size_t stride = (size_t)a.npay * a.ncp;
             double acc = 0.0;
-            int b = b0;
-            for (; b + 8 <= b1; b += 8) {       // 8 independent loads in flight, fixed add order
+            // batches of 8 unconditional loads (row index clamped, value masked): one memory
+            // latency per batch instead of one per row; fixed add order
+            for (int b = b0; b < b1; b += 8) {
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(b + u) * stride];
+                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(b + u, b1 - 1) * stride];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const bool in = (c >= s_rng[2 * (b + u)]) && (c < s_rng[2 * (b + u) + 1]);
+                    const int bb = min(b + u, b1 - 1);
+                    const bool in = (b + u < b1) && (c >= s_rng[2 * bb]) && (c < s_rng[2 * bb + 1]);
                     acc = acc + (in ? v[u] : 0.0);
                 }
-            }
-            for (; b < b1; ++b) {
-                const double v = src[(size_t)b * stride];
-                const bool in = (c >= s_rng[2 * b]) && (c < s_rng[2 * b + 1]);
-                acc = acc + (in ? v : 0.0);
             }
             s_seg[idx] = acc;
         }
@@ -81,6 +78,10 @@ __global__ void __launch_bounds__(COL_BLOCK) k_column(const ColArgs a)
             double tot = s_seg[col];
             for (int s = 1; s < a.nseg; ++s) tot = tot + s_seg[s * ncols + col];
             a.flux[col] = tot;
+            if ((MODE & COL_UPDATE) && STAGE != 4) {        // pm_flux[:, 1:-1] straight into LDS (:654)
+                const int p = col / a.ncp, c = col - p * a.ncp;
+                s_F[p * ng + 1 + c] = tot;
+            }
         }
         if (!(MODE & COL_UPDATE)) return;
         __syncthreads();
@@ -88,11 +89,13 @@ __global__ void __launch_bounds__(COL_BLOCK) k_column(const ColArgs a)
 
     if (STAGE != 4) {
         // pm_flux on interfaces, lib/libprop.py:653-660 (flux has ng-2 levels per component)
-        for (int i = tid; i < 2 * (ng - 2); i += COL_BLOCK) {
-            const int p = i / (ng - 2), c = i - p * (ng - 2);
-            s_F[p * ng + 1 + c] = a.flux[i];
+        if (!(MODE & COL_REDUCE)) {
+            for (int i = tid; i < 2 * (ng - 2); i += COL_BLOCK) {
+                const int p = i / (ng - 2), c = i - p * (ng - 2);
+                s_F[p * ng + 1 + c] = a.flux[i];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if (tid < 2) { s_F[tid * ng] = s_F[tid * ng + 1]; s_F[tid * ng + ng - 1] = s_F[tid * ng + ng - 2]; }
         __syncthreads();
         if (STAGE == 3 && a.out_flux)
@@ -173,21 +176,16 @@ __global__ void __launch_bounds__(COL_BLOCK) k_flux_reduce1(const Red1Args a)
         const int b0 = (int)((long long)seg * nr / a.nseg), b1 = (int)((long long)(seg + 1) * nr / a.nseg);
         const double *src = a.partial + (size_t)r0 * a.ncols + col;
         double acc = 0.0;
-        int b = b0;
-        for (; b + 4 <= b1; b += 4) {
-            double v[4];
+        for (int b = b0; b < b1; b += 8) {
+            double v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(b + u) * a.ncols];
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(b + u, b1 - 1) * a.ncols];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = (c >= s_rng[2 * (b + u)]) && (c < s_rng[2 * (b + u) + 1]);
+            for (int u = 0; u < 8; ++u) {
+                const int bb = min(b + u, b1 - 1);
+                const bool in = (b + u < b1) && (c >= s_rng[2 * bb]) && (c < s_rng[2 * bb + 1]);
                 acc = acc + (in ? v[u] : 0.0);
             }
-        }
-        for (; b < b1; ++b) {
-            const double v = src[(size_t)b * a.ncols];
-            const bool in = (c >= s_rng[2 * b]) && (c < s_rng[2 * b + 1]);
-            acc = acc + (in ? v : 0.0);
         }
         s_seg[idx] = acc;
     }

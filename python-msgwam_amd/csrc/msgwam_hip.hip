@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -93,6 +94,7 @@ struct msgw_ctx {
 
     // launch geometry + per-workgroup flux rows
     int blocks_per_cu = 4;
+    int prefetch = 0;                // register double-buffering in the ray-stage kernel
     int blocks = 0, tiles_per_block = 0;
     double *partial = nullptr;
     size_t partial_elems = 0;
@@ -142,6 +144,14 @@ int fail(msgw_ctx *c, int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                \
     } while (0)
 
+// the exact constant division (div_const) needs d's significand not to be all ones
+int markstein_ok(double d)
+{
+    uint64_t b;
+    std::memcpy(&b, &d, sizeof b);
+    return ((b & 0xFFFFFFFFFFFFFull) != 0xFFFFFFFFFFFFFull) && std::isfinite(d) && d > 0;
+}
+
 size_t stage_lds_bytes(int ng)
 {
     const int ni = ng - 2, nc = ng - 1, ncp = ng - 2;
@@ -156,7 +166,7 @@ size_t col_lds_bytes(int ng, int nseg, int ncols, int nblocks)
     return sizeof(double) * (size_t)(2 * ng + 2 * (ng - 1) + 2 * (ng - 2) + (size_t)nseg * ncols) +
            sizeof(int) * 2 * (size_t)nblocks + 16;
 }
-constexpr int RED1_GROUPS = 64;      // first-level reduce workgroups
+constexpr int RED1_GROUPS = 32;      // first-level reduce workgroups
 constexpr int RED1_MIN_ROWS = 128;   // below this the single-workgroup column kernel reads the rows itself
 
 int pick_nseg(int ncols)
@@ -262,6 +272,7 @@ StageArgs make_stage_args(msgw_ctx *c, double dt, unsigned flags)
     a.xg0 = c->xg0; a.inv_dzg = 1.0 / c->dzg;
     a.gs0 = c->gs0; a.inv_dzs = 1.0 / c->dzs;
     a.dzs = c->dzs;
+    a.mk_ok = markstein_ok(c->dzs);
     a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
                   c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0};
     a.c = ColPtrs{c->grid + 1, c->dudz, c->dvdz, c->slu, c->slv, c->grids, c->rhobar, c->slrho};
@@ -322,7 +333,9 @@ int launch_ray_kernel(msgw_ctx *c, K k, size_t lds, const StageArgs &a)
 template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
 int launch_stage_t(msgw_ctx *c, const StageArgs &a)
 {
-    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT>, stage_lds_bytes(c->ng), a);
+    if (c->prefetch && c->tiles_per_block > 1 && STAGE != 3)
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, (STAGE != 3)>, stage_lds_bytes(c->ng), a);
+    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false>, stage_lds_bytes(c->ng), a);
 }
 
 // mode: 0 plain, 1 online saturation, 2 direct (driver) saturation
@@ -584,8 +597,9 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
 int msgw_set_tuning(msgw_ctx *c, int blocks_per_cu, int graph_steps)
 {
     if (!c) return MSGW_ERR_ARG;
-    if (blocks_per_cu < 1 || blocks_per_cu > 32 || graph_steps < 0 || graph_steps > 64)
-        return fail(c, MSGW_ERR_ARG, "blocks_per_cu in [1,32], graph_steps in [0,64]");
+    if (blocks_per_cu < 1 || blocks_per_cu > 64 || graph_steps < 0 || graph_steps > 64)
+        return fail(c, MSGW_ERR_ARG, "blocks_per_cu in [1,64], graph_steps in [0,64]");
+    if (const char *e = std::getenv("MSGW_PREFETCH")) c->prefetch = std::atoi(e) ? 1 : 0;
     c->blocks_per_cu = blocks_per_cu;
     c->graph_steps = graph_steps;
     drop_graph(c);
@@ -723,6 +737,7 @@ int msgw_project(msgw_ctx *c, int var, const double *G, int nG, double *out)
     ProjArgs a{};
     a.n = c->n; a.nG = nG; a.var = var;
     a.bvf2 = std::pow(c->bvf, 2.0); a.f_uni = c->f_uni; a.dz = G[1] - G[0];
+    a.cdz = 1.0 / a.dz; a.mk_ok = markstein_ok(a.dz);
     a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
                   c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0};
     return run_projection(c, a, false, var == 0 ? 2 : 1, G, nG, out);
@@ -753,6 +768,7 @@ int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const doubl
         ProjArgs a{};
         a.n = n; a.nG = nG; a.var = var;
         a.bvf2 = std::pow(bvf, 2.0); a.f_uni = 0.0; a.dz = G[1] - G[0];
+        a.cdz = 1.0 / a.dz; a.mk_ok = markstein_ok(a.dz);
         a.e = ProjExplicit{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]};
         rc = run_projection(c, a, true, var == 0 ? 2 : 1, G, nG, out);
     }
