@@ -2,6 +2,7 @@
 // O(100..1000) levels).  Deterministic: per-workgroup flux rows are summed in
 // a fixed (segment, workgroup) order, independent of scheduling.
 #pragma once
+#include "column_math.h"
 #include "ray_kernels.h"
 
 namespace msgw {
@@ -18,7 +19,8 @@ struct ColArgs {
     const int *ranges;
     double *flux;         // [npay][ncp] reduced (this rank's) flux profile
     const double *rhobar, *pg;
-    double *uu, *vv, *q_uu, *q_vv;
+    ColIn in;             // column read  (may alias `out`: each level is read, then written, by one thread)
+    ColOut out;           // column written
     const double *xg;
     double *dudz, *dvdz, *slu, *slv;
     double *out_du, *out_dv, *out_flux;   // probe outputs (device)
@@ -33,7 +35,7 @@ constexpr int COL_UPDATE = 2;   // mean-flow tendencies / RK update / shear colu
 template <int STAGE, int MODE>
 __global__ void __launch_bounds__(COL_BLOCK) k_column(const ColArgs a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ng = a.ng, nc = ng - 1, ni = ng - 2;
     const int ncols = a.npay * a.ncp;
     double *s_F = lds;                      // [2][ng]
@@ -96,56 +98,32 @@ __global__ void __launch_bounds__(COL_BLOCK) k_column(const ColArgs a)
             }
             __syncthreads();
         }
-        if (tid < 2) { s_F[tid * ng] = s_F[tid * ng + 1]; s_F[tid * ng + ng - 1] = s_F[tid * ng + ng - 2]; }
+        column_flux_ends(tid, ng, s_F);
         __syncthreads();
-        if (STAGE == 3 && a.out_flux)
-            for (int i = tid; i < 2 * ng; i += COL_BLOCK) a.out_flux[i] = s_F[i];
-        for (int j = tid; j < nc; j += COL_BLOCK) {
-            const double gx = (s_F[j + 1] - s_F[j]) / a.dzg;                   // :663
-            const double gy = (s_F[ng + j + 1] - s_F[ng + j]) / a.dzg;
-            const double u = a.uu[j], v = a.vv[j];
-            const double rinv = 1.0 / a.rhobar[j];                              // rhobar**-1
-            double du = a.f0 * v - rinv * (a.pg[j] + gx);                       // :537
-            double dv = -a.f0 * u - rinv * (a.pg[nc + j] + gy);                 // :556
-            if (a.fixed_background) { du = 0.0; dv = 0.0; }
-            if (STAGE == 3) {
+        if (STAGE == 3) {                                   // probe: tendencies + flux out, no update
+            if (a.out_flux)
+                for (int i = tid; i < 2 * ng; i += COL_BLOCK) a.out_flux[i] = s_F[i];
+            for (int j = tid; j < nc; j += COL_BLOCK) {
+                double du, dv;
+                column_tendency(j, ng, a.f0, a.dzg, a.fixed_background, s_F, a.rhobar, a.pg,
+                                a.in.uu[j], a.in.vv[j], du, dv);
                 if (a.out_du) a.out_du[j] = du;
                 if (a.out_dv) a.out_dv[j] = dv;
-                s_u[j] = u; s_v[j] = v;
-            } else {
-                double qu, qv, un, vn;
-                if (STAGE == 0) {
-                    qu = a.dt * du; qv = a.dt * dv;
-                    un = u + qu / 3; vn = v + qv / 3;
-                } else if (STAGE == 1) {
-                    qu = a.dt * du - RK_A1 * a.q_uu[j]; qv = a.dt * dv - RK_A1 * a.q_vv[j];
-                    un = u + RK_B1 * qu; vn = v + RK_B1 * qv;
-                } else {
-                    qu = a.dt * du - RK_A2 * a.q_uu[j]; qv = a.dt * dv - RK_A2 * a.q_vv[j];
-                    un = u + RK_B2 * qu; vn = v + RK_B2 * qv;
-                }
-                a.q_uu[j] = qu; a.q_vv[j] = qv;
-                a.uu[j] = un; a.vv[j] = vn;
-                s_u[j] = un; s_v[j] = vn;
             }
+            return;
         }
-        if (STAGE == 3) return;
+        column_stage_all(STAGE, tid, COL_BLOCK, ng, a.dt, a.f0, a.dzg, a.fixed_background, s_F,
+                         a.rhobar, a.pg, a.in, a.out, true, s_u, s_v);
     } else {
-        for (int j = tid; j < nc; j += COL_BLOCK) { s_u[j] = a.uu[j]; s_v[j] = a.vv[j]; }
+        for (int j = tid; j < nc; j += COL_BLOCK) { s_u[j] = a.in.uu[j]; s_v[j] = a.in.vv[j]; }
     }
     __syncthreads();
     // shear on the interior interfaces, lib/libprop.py:352-353, and np.interp's slopes
-    for (int j = tid; j < ni; j += COL_BLOCK) {
-        const double du = (s_u[j + 1] - s_u[j]) / a.dzg;
-        const double dv = (s_v[j + 1] - s_v[j]) / a.dzg;
-        s_du[j] = du; s_dv[j] = dv;
-        a.dudz[j] = du; a.dvdz[j] = dv;
-    }
+    column_shear(tid, COL_BLOCK, ng, a.dzg, s_u, s_v, s_du, s_dv);
     __syncthreads();
-    for (int j = tid; j < ni - 1; j += COL_BLOCK) {
-        const double dx = a.xg[j + 1] - a.xg[j];
-        a.slu[j] = (s_du[j + 1] - s_du[j]) / dx;
-        a.slv[j] = (s_dv[j + 1] - s_dv[j]) / dx;
+    for (int j = tid; j < ni; j += COL_BLOCK) {
+        a.dudz[j] = s_du[j]; a.dvdz[j] = s_dv[j];
+        if (j < ni - 1) { a.slu[j] = column_slope(s_du, a.xg, j); a.slv[j] = column_slope(s_dv, a.xg, j); }
     }
 }
 
@@ -161,7 +139,7 @@ struct Red1Args {
 };
 __global__ void __launch_bounds__(COL_BLOCK) k_flux_reduce1(const Red1Args a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     double *s_seg = lds;                                              // [nseg][ncols]
     int *s_rng = reinterpret_cast<int *>(s_seg + (size_t)a.nseg * a.ncols);
     const int tid = threadIdx.x;

@@ -90,7 +90,8 @@ struct msgw_ctx {
            *vv = nullptr, *q_uu = nullptr, *q_vv = nullptr, *dudz = nullptr, *dvdz = nullptr,
            *slu = nullptr, *slv = nullptr, *slrho = nullptr, *flux = nullptr, *out_du = nullptr,
            *out_dv = nullptr, *out_flux = nullptr;
-    double dzg = 0, dzs = 0, xg0 = 0, gs0 = 0;
+    double *alt_uu = nullptr, *alt_vv = nullptr, *alt_q_uu = nullptr, *alt_q_vv = nullptr;   // 2nd column set
+    double dzg = 0, dzs = 0, xg0 = 0, gs0 = 0, xg_last = 0, gs_last = 0;
 
     // launch geometry + per-workgroup flux rows
     int blocks_per_cu = 4;
@@ -240,9 +241,9 @@ int ensure_partial(msgw_ctx *c, int blocks, size_t row_elems)
 
 // First level of the flux reduction (many workgroup rows -> RED1_GROUPS dense rows);
 // rewrites `a` so that the column kernel reads the second-level rows.
-int reduce_level1(msgw_ctx *c, ColArgs &a)
+int reduce_level1(msgw_ctx *c, ColArgs &a, bool force = false)
 {
-    if (a.nblocks < RED1_MIN_ROWS) return MSGW_OK;
+    if (a.nblocks < RED1_MIN_ROWS && !force) return MSGW_OK;
     Red1Args r{};
     r.nblocks = a.nblocks; r.npay = a.npay; r.ncp = a.ncp; r.ncols = a.npay * a.ncp;
     r.nseg = pick_nseg(r.ncols);
@@ -250,9 +251,10 @@ int reduce_level1(msgw_ctx *c, ColArgs &a)
     const int rows_per_group = (a.nblocks + RED1_GROUPS - 1) / RED1_GROUPS + 1;
     const size_t lds = sizeof(double) * (size_t)r.nseg * r.ncols + sizeof(int) * 2 * (size_t)rows_per_group + 16;
     if (int rc = ensure_lds(c, k_flux_reduce1, lds)) return rc;
-    hipLaunchKernelGGL(k_flux_reduce1, dim3(RED1_GROUPS), dim3(COL_BLOCK), lds, c->stream, r);
+    const int groups = a.nblocks < RED1_GROUPS ? a.nblocks : RED1_GROUPS;
+    hipLaunchKernelGGL(k_flux_reduce1, dim3(groups), dim3(COL_BLOCK), lds, c->stream, r);
     HIPCHK(c, hipGetLastError());
-    a.partial = c->row2; a.ranges = nullptr; a.nblocks = RED1_GROUPS;
+    a.partial = c->row2; a.ranges = nullptr; a.nblocks = groups;
     return MSGW_OK;
 }
 
@@ -271,6 +273,7 @@ StageArgs make_stage_args(msgw_ctx *c, double dt, unsigned flags)
     a.sat_rr_div = (flags & MSGW_DIRECT_SAT_QUIRK) ? 1.0 : dt;
     a.xg0 = c->xg0; a.inv_dzg = 1.0 / c->dzg;
     a.gs0 = c->gs0; a.inv_dzs = 1.0 / c->dzs;
+    a.xg_last = c->xg_last; a.gs_last = c->gs_last;
     a.dzs = c->dzs;
     a.mk_ok = markstein_ok(c->dzs);
     a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
@@ -278,6 +281,8 @@ StageArgs make_stage_args(msgw_ctx *c, double dt, unsigned flags)
     a.c = ColPtrs{c->grid + 1, c->dudz, c->dvdz, c->slu, c->slv, c->grids, c->rhobar, c->slrho};
     a.partial = c->partial;
     a.ranges = c->ranges;
+    a.col_pending = 0;
+    a.pg = c->pg; a.f0 = c->f0; a.dzg = c->dzg;
     return a;
 }
 
@@ -293,7 +298,8 @@ ColArgs make_col_args(msgw_ctx *c, double dt, unsigned flags)
     a.dt = dt; a.f0 = c->f0; a.dzg = c->dzg;
     a.partial = c->partial; a.ranges = c->ranges; a.flux = c->flux;
     a.rhobar = c->rhobar; a.pg = c->pg;
-    a.uu = c->uu; a.vv = c->vv; a.q_uu = c->q_uu; a.q_vv = c->q_vv;
+    a.in = ColIn{c->uu, c->vv, c->q_uu, c->q_vv};
+    a.out = ColOut{c->uu, c->vv, c->q_uu, c->q_vv};
     a.xg = c->grid + 1;
     a.dudz = c->dudz; a.dvdz = c->dvdz; a.slu = c->slu; a.slv = c->slv;
     a.out_du = c->out_du; a.out_dv = c->out_dv; a.out_flux = c->out_flux;
@@ -333,9 +339,11 @@ int launch_ray_kernel(msgw_ctx *c, K k, size_t lds, const StageArgs &a)
 template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
 int launch_stage_t(msgw_ctx *c, const StageArgs &a)
 {
+    if (c->ng - 2 > 128)   // tall columns: per-level sums stay in LDS (NH = 0)
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false, 0>, stage_lds_bytes(c->ng), a);
     if (c->prefetch && c->tiles_per_block > 1 && STAGE != 3)
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, (STAGE != 3)>, stage_lds_bytes(c->ng), a);
-    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false>, stage_lds_bytes(c->ng), a);
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, (STAGE != 3), 2>, stage_lds_bytes(c->ng), a);
+    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false, 2>, stage_lds_bytes(c->ng), a);
 }
 
 // mode: 0 plain, 1 online saturation, 2 direct (driver) saturation
@@ -412,26 +420,64 @@ int column_stage(msgw_ctx *c, const ColArgs &a0)
     return launch_column_t<STAGE, COL_REDUCE | COL_UPDATE>(c, a);
 }
 
-// Enqueue one RK3 step (lib/libprop.py:693-698) on the context's stream.
-int enqueue_step(msgw_ctx *c, double dt, unsigned flags, bool time_kernels)
+// Enqueue `count` RK3 steps (lib/libprop.py:693-698) on the context's stream.
+// Coupled mode chains the stages so that each stage's mean-flow update is applied in the
+// PROLOGUE of the next ray-stage kernel (all workgroups redo the tiny column update in LDS,
+// workgroup 0 publishes it to the other column set); only the very last update of the batch
+// runs as a standalone k_column, which always lands in the canonical set (c->uu, ...).
+//   per stage:  k_ray_stage -> k_flux_reduce1 [-> k_column<reduce> -> ncclAllReduce]
+int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_kernels)
 {
+    if (count <= 0) return MSGW_OK;
     const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
-    const StageArgs sa = make_stage_args(c, dt, flags);
+    StageArgs sa = make_stage_args(c, dt, flags);
     auto timed = [&](auto &&launch) -> int {
         c->time_next = time_kernels;
         const int rc = launch();
         c->time_next = false;
         return rc;
     };
-    if (flags & MSGW_FIXED_BACKGROUND)
-        return timed([&] { return launch_fixed(c, sa, mode); });
-    const ColArgs ca = make_col_args(c, dt, flags);
-    if (int rc = timed([&] { return launch_stage<0>(c, sa, mode); })) return rc;
-    if (int rc = column_stage<0>(c, ca)) return rc;
-    if (int rc = timed([&] { return launch_stage<1>(c, sa, mode); })) return rc;
-    if (int rc = column_stage<1>(c, ca)) return rc;
-    if (int rc = timed([&] { return launch_stage<2>(c, sa, mode); })) return rc;
-    return column_stage<2>(c, ca);
+    if (flags & MSGW_FIXED_BACKGROUND) {
+        for (int s = 0; s < count; ++s)
+            if (int rc = timed([&] { return launch_fixed(c, sa, mode); })) return rc;
+        return MSGW_OK;
+    }
+    const ColIn in_set[2] = {ColIn{c->uu, c->vv, c->q_uu, c->q_vv}, ColIn{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
+    const ColOut out_set[2] = {ColOut{c->uu, c->vv, c->q_uu, c->q_vv}, ColOut{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
+    int cur = 0;                       // set that holds the column BEFORE the pending update
+    bool pending = false;
+    int pend_stage = 0;
+    ColArgs rows{};                    // where the pending flux rows live
+    for (int step = 0; step < count; ++step) {
+        for (int s = 0; s < 3; ++s) {
+            sa.col_pending = pending ? 1 : 0;
+            sa.col_stage = pend_stage;
+            sa.col_rows = rows.partial;
+            sa.col_nrows = rows.nblocks;
+            sa.cin = in_set[cur];
+            sa.cout = out_set[cur ^ 1];
+            int rc = MSGW_OK;
+            if (s == 0) rc = timed([&] { return launch_stage<0>(c, sa, mode); });
+            else if (s == 1) rc = timed([&] { return launch_stage<1>(c, sa, mode); });
+            else rc = timed([&] { return launch_stage<2>(c, sa, mode); });
+            if (rc) return rc;
+            if (pending) cur ^= 1;     // workgroup 0 has published the updated column there
+            rows = make_col_args(c, dt, flags);
+            if ((rc = reduce_level1(c, rows, true))) return rc;            // -> dense rows in row2
+            if (c->nranks > 1) {       // local rows -> one flux row, summed over the ranks
+                if ((rc = launch_column_t<4, COL_REDUCE>(c, rows))) return rc;
+                if ((rc = allreduce_flux(c))) return rc;
+                rows.partial = c->flux; rows.ranges = nullptr; rows.nblocks = 1;
+            }
+            pending = true;
+            pend_stage = s;
+        }
+    }
+    // the last update of the batch: standalone, from set `cur` into the canonical set
+    rows.in = in_set[cur];
+    rows.out = out_set[0];
+    rows.nseg = pick_nseg(rows.npay * rows.ncp);
+    return launch_column_t<2, COL_REDUCE | COL_UPDATE>(c, rows);
 }
 
 int ready(msgw_ctx *c)
@@ -478,14 +524,14 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     CR(hipEventCreate(&c->ev1));
     double **rp[] = {&c->dens, &c->rr, &c->mm, &c->drr, &c->kk, &c->ll, &c->dmm, &c->vol, &c->fray,
                      &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0};
-    const size_t padded = ((size_t)nray_cap + 1) & ~(size_t)1;     // keep 16-B pairs in bounds
+    const size_t padded = (((size_t)nray_cap + TILE - 1) / TILE) * TILE;   // whole tiles: unconditional vector access
     for (double **p : rp) {
         CR(hipMalloc(p, padded * sizeof(double)));
         c->ray_bufs.push_back(*p);
     }
     // column: one allocation carved into equally sized slots of ng doubles (+ 2 for the flux output)
     const size_t slot = (size_t)ngrid + 2;
-    const int nslots = 18;
+    const int nslots = 24;
     CR(hipMalloc(&c->colbuf, slot * nslots * sizeof(double) * 2));
     CR(hipMemset(c->colbuf, 0, slot * nslots * sizeof(double) * 2));
     double *b = c->colbuf;
@@ -495,6 +541,7 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     c->slu = b; b += slot; c->slv = b; b += slot; c->slrho = b; b += slot;
     c->flux = b; b += 2 * slot; c->out_du = b; b += slot; c->out_dv = b; b += slot;
     c->out_flux = b; b += 2 * slot;
+    c->alt_uu = b; b += slot; c->alt_vv = b; b += slot; c->alt_q_uu = b; b += slot; c->alt_q_vv = b; b += slot;
 #undef CR
     c->cnt.ngrid = ngrid;
     c->cnt.nranks = 1;
@@ -551,6 +598,8 @@ int msgw_set_column(msgw_ctx *c, const double *grid, const double *grids, const 
     c->dzs = grids[1] - grids[0];                    // the same on grids     (:123 with G = grids)
     c->xg0 = grid[1];
     c->gs0 = grids[0];
+    c->xg_last = grid[ng - 2];                       // last point of grid[1:-1]
+    c->gs_last = grids[nc - 1];
     if (!(c->dzg > 0) || !(c->dzs > 0)) return fail(c, MSGW_ERR_ARG, "grid must be increasing");
     hipLaunchKernelGGL(k_rho_slopes, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, c->grids, c->rhobar, c->slrho);
     HIPCHK(c, hipGetLastError());
@@ -578,6 +627,18 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (long long)n,
                        c->q_rr, c->q_mm, c->q_dens, c->drr, c->dmm, c->vol, c->pvf);
     HIPCHK(c, hipGetLastError());
+    // inert padding up to a whole tile (finite, never deposited: validity is index < n)
+    const long long n_pad = ((n + TILE - 1) / TILE) * TILE;
+    if (n_pad > n) {
+        struct { double *p; double v; } pad[] = {
+            {c->dens, 0.0}, {c->rr, 0.0}, {c->mm, 1.0}, {c->drr, 1.0}, {c->kk, 1.0}, {c->ll, 0.0},
+            {c->dmm, 0.0}, {c->vol, 0.0}, {c->fray, 0.0}, {c->pvf, 1.0}, {c->q_rr, 0.0}, {c->q_mm, 0.0},
+            {c->q_dens, 0.0}, {c->rr0, 0.0}, {c->mm0, 1.0}};
+        for (auto &x : pad)
+            hipLaunchKernelGGL(k_fill_range, dim3((unsigned)((n_pad - n + 255) / 256)), dim3(256), 0, c->stream,
+                               x.p, (long long)n, n_pad, x.v);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // a single latitude for all rays (the 1-D column case, raytracer.py:87) keeps f in a scalar
     bool uni = true;
@@ -630,7 +691,7 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
             bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             int rc = MSGW_OK;
             if (ok) {
-                for (int s = 0; s < c->graph_steps && rc == MSGW_OK; ++s) rc = enqueue_step(c, dt, gflags, false);
+                rc = enqueue_steps(c, dt, gflags, c->graph_steps, false);
                 hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
                 ok = (rc == MSGW_OK) && (e == hipSuccess) && c->graph;
             }
@@ -648,8 +709,7 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
             done += c->g_steps;
         }
     }
-    for (; done < nsteps; ++done)
-        if (int rc = enqueue_step(c, dt, gflags, time_kernels)) return rc;
+    if (int rc = enqueue_steps(c, dt, gflags, nsteps - done, time_kernels)) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
     c->cnt.graph_steps = c->gexec ? c->g_steps : 0;
@@ -754,10 +814,12 @@ int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const doubl
     const double *h[11] = {dens, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, fray};
     for (const double *p : h) if (!p) return fail(c, MSGW_ERR_ARG, "NULL array");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t padded = ((size_t)n + 1) & ~(size_t)1;
+    const size_t padded = (((size_t)n + TILE - 1) / TILE) * TILE;
     double *buf = nullptr;
     HIPCHK(c, hipMalloc(&buf, sizeof(double) * padded * 11));
     int rc = MSGW_OK;
+    if (hipMemsetAsync(buf, 0, sizeof(double) * padded * 11, c->stream) != hipSuccess)
+        rc = fail(c, MSGW_ERR_HIP, "memset failed in msgw_project_arrays");
     const double *d[11];
     for (int i = 0; i < 11 && rc == MSGW_OK; ++i) {
         d[i] = buf + padded * i;
@@ -799,7 +861,7 @@ int msgw_saturation(msgw_ctx *c, int64_t n, double dt, int direct, const double 
         SatArgs a{};
         a.n = n; a.nc = c->ng - 1; a.direct = direct ? 1 : 0; a.dt = dt;
         a.bvf2 = std::pow(c->bvf, 2.0); a.f0sq = std::pow(c->f0, 2.0); a.sat_c = std::pow(c->kappa, 2.0) * .5;
-        a.gs0 = c->gs0; a.inv_dzs = 1.0 / c->dzs;
+        a.gs0 = c->gs0; a.gs_last = c->gs_last; a.inv_dzs = 1.0 / c->dzs;
         const double *b = buf;
         a.dens = b; a.rr = b + n; a.rr_st = b + 2 * n; a.drr = b + 3 * n; a.drr_st = b + 4 * n;
         a.kk = b + 5 * n; a.ll = b + 6 * n; a.mm = b + 7 * n; a.mm_st = b + 8 * n;

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <climits>
 #include <cstdint>
+#include "column_math.h"
 
 namespace msgw {
 
@@ -16,12 +17,6 @@ constexpr int RPT = 2;               // rays per lane -> 16-B global accesses
 constexpr int TILE = BLOCK * RPT;    // rays per workgroup iteration
 constexpr int SPAN_MAX = 8;          // widest per-wave level span on the shuffle path
 constexpr int COL_BLOCK = 1024;      // the column kernel is one workgroup
-
-// Williamson RK3 as python evaluates it (lib/libprop.py:693-698)
-constexpr double RK_A1 = 5.0 / 9.0;
-constexpr double RK_A2 = 153.0 / 128.0;
-constexpr double RK_B1 = 15.0 / 16.0;
-constexpr double RK_B2 = 8.0 / 15.0;
 
 struct RayPtrs {
     double *dens, *rr, *mm;                        // evolving slots 0, 3, 7
@@ -53,13 +48,32 @@ struct StageArgs {
     double sat_rr_div;    // 1.0 (driver quirk raytracer.py:184) or dt
     double xg0, inv_dzg;  // index guess on xg
     double gs0, inv_dzs;  // index guess on grids
+    double xg_last, gs_last;   // last abscissa of each table (first = xg0 / gs0)
     double dzs;           // grids[1]-grids[0]  (:123 with G = grids)
     int mk_ok;            // RN(1/dzs) usable for the exact constant division (see div_const)
     RayPtrs r;
     ColPtrs c;
     double *partial;      // [blocks][2][ng-2] per-workgroup flux rows
     int *ranges;          // [blocks][2] touched level range of each row
+    // Pending mean-flow update of the PREVIOUS RK stage, applied in this kernel's prologue by
+    // every workgroup in LDS (workgroup 0 also publishes the new column to cout):
+    int col_pending;      // 0: shear tables are read from c.dudz..; 1: apply the update below first
+    int col_stage;        // RK stage (0, 1, 2) of that update
+    int col_nrows;        // dense flux rows to add up (fixed order) ...
+    const double *col_rows;   // ... [col_nrows][2*(ng-2)]
+    const double *pg;     // pressure gradient [2][ng-1]
+    double f0, dzg;       // config Coriolis parameter (:535), grid[1]-grid[0] (:349, :662)
+    ColIn cin;            // column before the update (never written by this launch)
+    ColOut cout;          // column after the update (written by workgroup 0 only)
+#ifdef MSGW_STAMP
+    unsigned long long *stamps;   // diagnostic build only: [blocks][8] wall-clock stamps
+#endif
 };
+#ifdef MSGW_STAMP
+#define MSGW_STAMP_AT(k) do { if (threadIdx.x == 0 && a.stamps) a.stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define MSGW_STAMP_AT(k) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------ cross-lane
 template <int CTRL>
@@ -112,22 +126,18 @@ __device__ __forceinline__ int wave_max(int v)
 }
 
 // ------------------------------------------------------------------ global access
-__device__ __forceinline__ void load2(const double *p, long long i0, bool v0, bool v1,
-                                      double (&out)[2], double fill)
+// Every per-ray array is allocated and initialised up to a whole number of tiles (the host pads
+// with inert rays), so all accesses are UNCONDITIONAL 16-B vector accesses: a conditional
+// load makes hipcc branch around it and wait vmcnt(0) per load, which serialises the nine
+// streams of a tile into nine memory round trips (measured: 27 us vs 16 us per launch).
+__device__ __forceinline__ void load2(const double *p, long long i0, double (&out)[2])
 {
-    if (v1) {
-        const double2 t = *reinterpret_cast<const double2 *>(p + i0);   // 16 B per lane
-        out[0] = t.x; out[1] = t.y;
-    } else {
-        out[0] = v0 ? p[i0] : fill;
-        out[1] = fill;
-    }
+    const double2 t = *reinterpret_cast<const double2 *>(p + i0);       // 16 B per lane
+    out[0] = t.x; out[1] = t.y;
 }
-__device__ __forceinline__ void store2(double *p, long long i0, bool v0, bool v1,
-                                       const double (&v)[2])
+__device__ __forceinline__ void store2(double *p, long long i0, const double (&v)[2])
 {
-    if (v1) *reinterpret_cast<double2 *>(p + i0) = make_double2(v[0], v[1]);
-    else if (v0) p[i0] = v[0];
+    *reinterpret_cast<double2 *>(p + i0) = make_double2(v[0], v[1]);
 }
 
 // ------------------------------------------------------------------ np.interp on an LDS column
@@ -135,25 +145,30 @@ __device__ __forceinline__ void store2(double *p, long long i0, bool v0, bool v1
 // end values outside [xp[0], xp[n-1]], fp[j] exactly when x == xp[j], otherwise
 // slope[j]*(x - xp[j]) + fp[j] with slope[j] = (fp[j+1]-fp[j])/(xp[j+1]-xp[j])
 // (precomputed by the column kernel with the same expression).
-// Returns the bracket index j (0..n-1) and a mode: 0 interior, 1 take fp[j].
-__device__ __forceinline__ int interp_locate(double x, const double *xp, int n,
-                                             double x0, double inv_dx, int &mode)
+// locate: bracket index j with xp[j] <= x < xp[j+1] from a uniform-grid guess plus an exact
+// fix-up against the real abscissae (so any monotone grid works; the fix-up loops run 0 times
+// away from cell boundaries).  `flat` != 0 means "take fp[j] as is" (outside the table, on its
+// last point, or exactly on a point).  NaN falls through to slope*(NaN - xj) + fp = NaN.
+struct Bracket { int j; int flat; double xj; };
+__device__ __forceinline__ Bracket interp_locate(double x, const double *xp, int n, double x_first,
+                                                 double x_last, double x0, double inv_dx)
 {
-    if (x > xp[n - 1]) { mode = 1; return n - 1; }
-    if (x < xp[0]) { mode = 1; return 0; }
-    int j = (int)((x - x0) * inv_dx);              // uniform-grid guess, then exact fix-up
-    j = min(max(j, 0), n - 1);
-    while (j > 0 && x < xp[j]) --j;
-    while (j < n - 1 && x >= xp[j + 1]) ++j;
-    mode = (j == n - 1 || x == xp[j]) ? 1 : 0;
-    return j;
+    Bracket b;
+    int j = (int)((x - x0) * inv_dx);
+    j = min(max(j, 0), n - 2);
+    double xj = xp[j], xj1 = xp[j + 1];
+    while (x < xj && j > 0) { --j; xj1 = xj; xj = xp[j]; }
+    while (x >= xj1 && j < n - 2) { ++j; xj = xj1; xj1 = xp[j + 1]; }
+    const bool top = x >= x_last;                   // beyond or on the last point -> fp[n-1]
+    b.j = top ? n - 1 : j;
+    b.xj = xj;
+    b.flat = (top || x < x_first || x == xj) ? 1 : 0;
+    return b;
 }
-__device__ __forceinline__ double interp_eval(double x, int j, int mode, const double *xp,
-                                              const double *fp, const double *sl)
+__device__ __forceinline__ double interp_eval(double x, const Bracket &b, double fpj, double slj)
 {
-    if (x != x) return x;                          // NaN in -> NaN out
-    if (mode) return fp[j];
-    return sl[j] * (x - xp[j]) + fp[j];
+    const double lin = slj * (x - b.xj) + fpj;
+    return b.flat ? fpj : lin;
 }
 
 // numpy `.astype(int)` on x86-64 (lib/libprop.py:124-125) kept in the double
@@ -198,21 +213,41 @@ __device__ __forceinline__ void deposit_indices(double lo, double up, bool valid
     if (ood || !valid) { nlo = 0; nup = 0; }                 // :135, :153-154
 }
 
-template <int NP>
+// NH > 0: the wave keeps its level sums in NH lane-distributed registers per payload (lane L of
+// register h owns level 64*h + L), so the per-level result of the DPP reduction is added with a
+// predicated VALU add instead of a lane-0 LDS read-modify-write; flush_acc() folds them into the
+// wave's LDS row once per workgroup.  NH == 0 (columns with more than 128 levels): LDS RMW.
+#ifdef MSGW_STAMP
+__device__ unsigned long long g_dbg_levels, g_dbg_tiles, g_dbg_wide;
+#endif
+template <int NP, int NH>
 __device__ __forceinline__ void deposit_tile(const double (&lo)[RPT], const double (&up)[RPT],
                                              const int (&nlo)[RPT], const int (&nup)[RPT],
                                              const double (&vol)[RPT], const double (&pay)[NP][RPT],
                                              const double *sG, double dz, double cdz, int ok,
-                                             double *row, int ncp, int lane, int &wmin, int &wmax)
+                                             double *row, int ncp, int lane, int &wmin, int &wmax,
+                                             double (&acc)[NP][NH > 0 ? NH : 1])
 {
     int mylo = INT_MAX, myhi = INT_MIN;
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
         if (nup[r] > nlo[r]) { mylo = min(mylo, nlo[r]); myhi = max(myhi, nup[r]); }
+#if defined(MSGW_ABLATE) && MSGW_ABLATE == 4
+    const int wlo = __builtin_amdgcn_readfirstlane(mylo), whi = __builtin_amdgcn_readfirstlane(myhi);
+#else
     const int wlo = wave_min(mylo), whi = wave_max(myhi);    // wave-uniform
+#endif
     if (whi <= wlo) return;
     wmin = min(wmin, wlo);
     wmax = max(wmax, whi);
+#ifdef MSGW_STAMP
+    if (lane == 0) { atomicAdd(&g_dbg_levels, (unsigned long long)(whi - wlo)); atomicAdd(&g_dbg_tiles, 1ull);
+                     if (whi - wlo > SPAN_MAX) atomicAdd(&g_dbg_wide, 1ull); }
+#endif
+#if defined(MSGW_ABLATE) && MSGW_ABLATE == 1
+    asm volatile("" :: "v"(lo[0]), "v"(up[1]), "v"(vol[0]), "v"(pay[0][0]), "v"(pay[NP - 1][1]));
+    return;
+#endif
     if (whi - wlo <= SPAN_MAX) {
         for (int c = wlo; c < whi; ++c) {                    // uniform trip count: all lanes stay
             const double g0 = sG[c], g1 = sG[c + 1];         // LDS broadcast reads
@@ -221,18 +256,28 @@ __device__ __forceinline__ void deposit_tile(const double (&lo)[RPT], const doub
             for (int p = 0; p < NP; ++p) s[p] = 0.0;
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
-                if (c >= nlo[r] && c < nup[r]) {
-                    const double zmin = (g0 > lo[r]) ? g0 : lo[r];          // :157
-                    const double zmax = (g1 < up[r]) ? g1 : up[r];          // :158
-                    const double wv = div_const(fabs(zmax - zmin), dz, cdz, ok) * vol[r];   // :160, :162
+                const bool in = (c >= nlo[r]) && (c < nup[r]);
+                const double zmin = (g0 > lo[r]) ? g0 : lo[r];          // :157
+                const double zmax = (g1 < up[r]) ? g1 : up[r];          // :158
+                const double wv = div_const(fabs(zmax - zmin), dz, cdz, ok) * vol[r];   // :160, :162
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) s[p] = s[p] + wv * pay[p][r];
-                }
+                for (int p = 0; p < NP; ++p) s[p] = s[p] + (in ? wv * pay[p][r] : 0.0);
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
+#if defined(MSGW_ABLATE) && MSGW_ABLATE == 2
+                const double t = s[p];
+#else
                 const double t = wave_sum(s[p]);
-                if (lane == 0) row[p * ncp + c] += t;
+#endif
+                if (NH > 0) {
+                    const double mine = (lane == (c & 63)) ? t : 0.0;
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        if ((c >> 6) == h) acc[p][h] = acc[p][h] + mine;     // uniform branch
+                } else if (lane == 0) {
+                    row[p * ncp + c] += t;
+                }
             }
         }
     } else {
@@ -250,6 +295,21 @@ __device__ __forceinline__ void deposit_tile(const double (&lo)[RPT], const doub
             }
         }
     }
+}
+
+// fold a wave's register accumulators into its LDS row (after its own LDS atomics, in order)
+template <int NP, int NH>
+__device__ __forceinline__ void flush_acc(double *row, int ncp, int lane,
+                                          const double (&acc)[NP][NH > 0 ? NH : 1])
+{
+    if (NH == 0) return;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int c = 64 * h + lane;
+            if (c < ncp) row[p * ncp + c] += acc[p][h];
+        }
 }
 
 // Sum the WAVES private rows in wave order and write this workgroup's row
@@ -319,67 +379,109 @@ __device__ __forceinline__ void load_tile(TileRegs &t, const StageArgs &a, long 
     t.i0 = base + 2 * tid;
     t.v0 = t.i0 < a.n;
     t.v1 = t.i0 + 1 < a.n;
-    load2(a.r.rr, t.i0, t.v0, t.v1, t.rr, 0.0);
-    load2(a.r.mm, t.i0, t.v0, t.v1, t.mm, 1.0);
-    load2(a.r.kk, t.i0, t.v0, t.v1, t.kk, 1.0);
-    load2(a.r.ll, t.i0, t.v0, t.v1, t.ll, 0.0);
-    if (DEPOSIT || SAT || (DIRECT && STAGE == 2)) load2(a.r.dens, t.i0, t.v0, t.v1, t.dens, 0.0);
+    load2(a.r.rr, t.i0, t.rr);
+    load2(a.r.mm, t.i0, t.mm);
+    load2(a.r.kk, t.i0, t.kk);
+    load2(a.r.ll, t.i0, t.ll);
+    if (DEPOSIT || SAT || (DIRECT && STAGE == 2)) load2(a.r.dens, t.i0, t.dens);
     if (DEPOSIT) {
-        load2(a.r.drr, t.i0, t.v0, t.v1, t.drr, 1.0);
-        load2(a.r.vol, t.i0, t.v0, t.v1, t.vol, 0.0);
+        load2(a.r.drr, t.i0, t.drr);
+        load2(a.r.vol, t.i0, t.vol);
     }
-    if (FVEC) load2(a.r.fray, t.i0, t.v0, t.v1, t.ff, 0.0);
-    if (NEED_RHO) load2(a.r.pvf, t.i0, t.v0, t.v1, t.pvf, 1.0);
+    if (FVEC) load2(a.r.fray, t.i0, t.ff);
+    if (NEED_RHO) load2(a.r.pvf, t.i0, t.pvf);
     if (STAGE == 1 || STAGE == 2) {
-        load2(a.r.q_rr, t.i0, t.v0, t.v1, t.qr, 0.0);
-        load2(a.r.q_mm, t.i0, t.v0, t.v1, t.qm, 0.0);
-        if (SAT) load2(a.r.q_dens, t.i0, t.v0, t.v1, t.qd, 0.0);
+        load2(a.r.q_rr, t.i0, t.qr);
+        load2(a.r.q_mm, t.i0, t.qm);
+        if (SAT) load2(a.r.q_dens, t.i0, t.qd);
     }
     if (DIRECT && STAGE == 2) {
-        load2(a.r.rr0, t.i0, t.v0, t.v1, t.rr0, 0.0);
-        load2(a.r.mm0, t.i0, t.v0, t.v1, t.mm0, 1.0);
+        load2(a.r.rr0, t.i0, t.rr0);
+        load2(a.r.mm0, t.i0, t.mm0);
     }
 }
 
 // PREFETCH: keep a second register set and issue tile t+1's loads before tile t's math
 // (costs ~50 VGPRs, i.e. occupancy); without it a workgroup relies on the other resident
 // workgroups to cover its load latency.  Picked per launch by the host (MSGW_PREFETCH).
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool PREFETCH>
-__global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool PREFETCH, int NH = 2>
+__global__ void __launch_bounds__(BLOCK, PREFETCH ? 4 : 1) k_ray_stage(const StageArgs a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
     constexpr bool NEED_RHO = SAT || (DIRECT && STAGE == 2);
-    double *s_xg = lds, *s_dudz = s_xg + ni, *s_dvdz = s_dudz + ni, *s_slu = s_dvdz + ni,
-           *s_slv = s_slu + ni;
-    double *s_gs = s_slv + ni;                               // [nc]   (DEPOSIT or NEED_RHO)
-    double *s_rho = s_gs + nc, *s_slrho = s_rho + nc;        // [nc] each (NEED_RHO)
-    double *s_rows = s_slrho + nc;                           // [WAVES][2][ncp] (DEPOSIT)
+    // LDS: [sh: ni x {dudz, slu, dvdz, slv}] [rho2: nc x {rhobar, slope}] [xg: ni] [gs: nc] [rows] [rng]
+    double4 *s_sh = reinterpret_cast<double4 *>(lds);
+    double2 *s_rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);          // (NEED_RHO)
+    double *s_xg = lds + 4 * ni + 2 * nc;
+    double *s_gs = s_xg + ni;                                // [nc]   (DEPOSIT or NEED_RHO)
+    double *s_rows = s_gs + nc;                              // [WAVES][2][ncp] (DEPOSIT)
     int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * 2 * ncp);
+    // prologue scratch aliases the per-wave rows (zeroed afterwards): F [2][ng], u, v [nc], du, dv [ni]
+    double *s_F = s_rows, *s_u = s_F + 2 * ng, *s_v = s_u + nc, *s_du = s_v + nc, *s_dv = s_du + ni;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
 
+    MSGW_STAMP_AT(0);
     // the first tile's ray loads go out before the column is staged: both latencies overlap
     TileRegs cur, nxt;
     load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, tile0 * (long long)TILE, tid);
 
-    for (int i = tid; i < ni; i += BLOCK) {
-        s_xg[i] = a.c.xg[i]; s_dudz[i] = a.c.dudz[i]; s_dvdz[i] = a.c.dvdz[i];
-        if (i < ni - 1) { s_slu[i] = a.c.slu[i]; s_slv[i] = a.c.slv[i]; }
+    for (int i = tid; i < ni; i += BLOCK) s_xg[i] = a.c.xg[i];
+    if (DEPOSIT && a.col_pending) {
+        // (1) finish the flux reduction: add the dense rows in row order (8 loads in flight)
+        const int ncols = 2 * ncp;
+        for (int col = tid; col < ncols; col += BLOCK) {
+            double tot = 0.0;
+            for (int r0 = 0; r0 < a.col_nrows; r0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = a.col_rows[(size_t)min(r0 + u, a.col_nrows - 1) * ncols + col];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tot = tot + ((r0 + u < a.col_nrows) ? v[u] : 0.0);
+            }
+            const int p = col / ncp, c = col - p * ncp;
+            s_F[p * ng + 1 + c] = tot;                       // pm_flux[:, 1:-1]  (:654)
+        }
+        __syncthreads();
+        column_flux_ends(tid, ng, s_F);
+        __syncthreads();
+        // (2) RK stage of uu, vv (:665-666, :693-698); workgroup 0 publishes the new column
+        column_stage_all(a.col_stage, tid, BLOCK, ng, a.dt, a.f0, a.dzg, 0, s_F, a.c.rhobar, a.pg,
+                         a.cin, a.cout, blockIdx.x == 0, s_u, s_v);
+        __syncthreads();
+        // (3) shear + np.interp slopes straight into the packed LDS table
+        column_shear(tid, BLOCK, ng, a.dzg, s_u, s_v, s_du, s_dv);
+        __syncthreads();
+        for (int i = tid; i < ni; i += BLOCK) {
+            const bool in = i < ni - 1;
+            s_sh[i] = make_double4(s_du[i], in ? column_slope(s_du, s_xg, i) : 0.0,
+                                   s_dv[i], in ? column_slope(s_dv, s_xg, i) : 0.0);
+        }
+        __syncthreads();                                     // scratch is re-used as the wave rows below
+    } else {
+        for (int i = tid; i < ni; i += BLOCK) {
+            const bool in = i < ni - 1;                      // the last point has no slope (never used)
+            s_sh[i] = make_double4(a.c.dudz[i], in ? a.c.slu[i] : 0.0, a.c.dvdz[i], in ? a.c.slv[i] : 0.0);
+        }
     }
     if (DEPOSIT || NEED_RHO)
         for (int i = tid; i < nc; i += BLOCK) s_gs[i] = a.c.grids[i];
     if (NEED_RHO)
-        for (int i = tid; i < nc; i += BLOCK) {
-            s_rho[i] = a.c.rhobar[i];
-            if (i < nc - 1) s_slrho[i] = a.c.slrho[i];
-        }
+        for (int i = tid; i < nc; i += BLOCK)
+            s_rho2[i] = make_double2(a.c.rhobar[i], (i < nc - 1) ? a.c.slrho[i] : 0.0);
     if (DEPOSIT)
         for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) s_rows[i] = 0.0;
     __syncthreads();
+    MSGW_STAMP_AT(1);
 
     int wmin = INT_MAX, wmax = INT_MIN;
+    double acc[2][NH > 0 ? NH : 1];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int h = 0; h < (NH > 0 ? NH : 1); ++h) acc[p][h] = 0.0;
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = (tile0 + t) * (long long)TILE;
         if (base >= a.n) break;                              // workgroup-uniform
@@ -394,8 +496,8 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
         double (&pvf)[2] = cur.pvf, (&qr)[2] = cur.qr, (&qm)[2] = cur.qm, (&qd)[2] = cur.qd;
         double (&rr0)[2] = cur.rr0, (&mm0)[2] = cur.mm0;
         if (DIRECT && STAGE == 0) {                          // keep the start-of-step rr, mm
-            store2(a.r.rr0, i0, v0, v1, rr);
-            store2(a.r.mm0, i0, v0, v1, mm);
+            store2(a.r.rr0, i0, rr);
+            store2(a.r.mm0, i0, mm);
         }
 
         double lo[2], up[2], pay[2][2], nrr[2], nmm[2], ndens[2];
@@ -407,10 +509,10 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
             double kh2, m2, vk2, om, cgr;
             dispersion(kk[r], ll[r], mm[r], f2, a.bvf2, kh2, m2, vk2, om, cgr);   // :635-636
             const double st_rr = .5 * (cgr + cgr);                                  // :640
-            int mode;
-            const int j = interp_locate(rr[r], s_xg, ni, a.xg0, a.inv_dzg, mode);
-            const double gu = interp_eval(rr[r], j, mode, s_xg, s_dudz, s_slu);     // :355
-            const double gv = interp_eval(rr[r], j, mode, s_xg, s_dvdz, s_slv);     // :356
+            const Bracket bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
+            const double4 sh = s_sh[bk.j];                                          // {dudz, slu, dvdz, slv}
+            const double gu = interp_eval(rr[r], bk, sh.x, sh.y);                   // :355
+            const double gv = interp_eval(rr[r], bk, sh.z, sh.w);                   // :356
             const double gradient = kk[r] * gu + ll[r] * gv;                        // :517
             // :519-520: cg_lambda = cg_phi = 0 with HPROP off; the reference's division of that
             // zero by (RAD_EARTH + rr) only matters for rr == -RAD_EARTH and is not reproduced.
@@ -419,9 +521,9 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
             if (SAT) {                                                              // :647-651 -> :561-615
                 const double rr_f = rr[r] + st_rr * a.dt;                           // :591
                 const double mm_f = mm[r] + st_mm * a.dt;                           // :593
-                int md;
-                const int jr = interp_locate(rr_f, s_gs, nc, a.gs0, a.inv_dzs, md);
-                const double rho_f = interp_eval(rr_f, jr, md, s_gs, s_rho, s_slrho);   // :595
+                const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+                const double2 rh = s_rho2[br.j];                                   // {rhobar, slope}
+                const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);   // :595
                 const double omh = a.same_f ? om : sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);   // :597
                 const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);  // :601
                 if (maxd < dens[r] * pvf[r]) st_dens = (maxd - dens[r]) / a.dt;     // :604, :613
@@ -429,7 +531,11 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
             if (DEPOSIT) {
                 lo[r] = rr[r] - .5 * drr[r];                                        // :655
                 up[r] = rr[r] + .5 * drr[r];
+#if defined(MSGW_ABLATE) && MSGW_ABLATE == 3
+                nlo[r] = (int)(lo[r] * a.inv_dzs); nup[r] = nlo[r] + 1;
+#else
                 deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, a.inv_dzs, a.mk_ok, nc - 2, nlo[r], nup[r]);
+#endif
                 // :148-149.  The reference evaluates cg_rr at .5*((mm-.5*dmm)+(mm+.5*dmm)), which
                 // equals mm to within 1 ulp; the stage's own cgr is reused here.
                 pay[0][r] = cgr * kk[r] * dens[r];
@@ -460,9 +566,9 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
                     const double mm_st = (nmm[r] - mm0[r]) / a.dt;                  // raytracer.py:187
                     const double rr_f = rr0[r] + rr_st * a.dt;
                     const double mm_f = mm0[r] + mm_st * a.dt;
-                    int md;
-                    const int jr = interp_locate(rr_f, s_gs, nc, a.gs0, a.inv_dzs, md);
-                    const double rho_f = interp_eval(rr_f, jr, md, s_gs, s_rho, s_slrho);
+                    const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+                    const double2 rh = s_rho2[br.j];                                   // {rhobar, slope}
+                    const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);   // :595
                     const double m02 = mm0[r] * mm0[r];
                     const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m02) / (kh2 + m02));   // :597 (old mm)
                     const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
@@ -471,30 +577,38 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
             }
         }
 
+#ifdef MSGW_STAMP
+        asm volatile("" :: "v"(nrr[0]), "v"(nmm[1]));
+        MSGW_STAMP_AT(2 + 2 * (t & 1));
+#endif
         if (STAGE == 3) {
-            store2(a.r.q_rr, i0, v0, v1, nrr);
-            store2(a.r.q_mm, i0, v0, v1, nmm);
-            store2(a.r.q_dens, i0, v0, v1, ndens);
+            store2(a.r.q_rr, i0, nrr);
+            store2(a.r.q_mm, i0, nmm);
+            store2(a.r.q_dens, i0, ndens);
         } else {
-            store2(a.r.rr, i0, v0, v1, nrr);
-            store2(a.r.mm, i0, v0, v1, nmm);
-            if (SAT || (DIRECT && STAGE == 2)) store2(a.r.dens, i0, v0, v1, ndens);
+            store2(a.r.rr, i0, nrr);
+            store2(a.r.mm, i0, nmm);
+            if (SAT || (DIRECT && STAGE == 2)) store2(a.r.dens, i0, ndens);
             if (STAGE != 2) {
-                store2(a.r.q_rr, i0, v0, v1, qr);
-                store2(a.r.q_mm, i0, v0, v1, qm);
-                if (SAT) store2(a.r.q_dens, i0, v0, v1, qd);
+                store2(a.r.q_rr, i0, qr);
+                store2(a.r.q_mm, i0, qm);
+                if (SAT) store2(a.r.q_dens, i0, qd);
             }
         }
         if (DEPOSIT)
-            deposit_tile<2>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok,
-                            s_rows + wave * 2 * ncp, ncp, lane, wmin, wmax);
+            deposit_tile<2, NH>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok,
+                                s_rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
+        MSGW_STAMP_AT(3 + 2 * (t & 1));
         if (more) {
             if (PREFETCH) cur = nxt;
             else load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, base + TILE, tid);
         }
     }
-    if (DEPOSIT)
+    if (DEPOSIT) {
+        flush_acc<2, NH>(s_rows + wave * 2 * ncp, ncp, lane, acc);
         flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
+    }
+    MSGW_STAMP_AT(6);
 }
 
 // ------------------------------------------------------------------ K1f: fixed background, whole RK3 step in registers
@@ -504,21 +618,23 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
 template <bool SAT, bool FVEC, bool DIRECT>
 __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ng = a.ng, ni = ng - 2, nc = ng - 1;
     constexpr bool NEED_RHO = SAT || DIRECT;
-    double *s_xg = lds, *s_dudz = s_xg + ni, *s_dvdz = s_dudz + ni, *s_slu = s_dvdz + ni,
-           *s_slv = s_slu + ni;
-    double *s_gs = s_slv + ni, *s_rho = s_gs + nc, *s_slrho = s_rho + nc;
+    double4 *s_sh = reinterpret_cast<double4 *>(lds);
+    double2 *s_rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);
+    double *s_xg = lds + 4 * ni + 2 * nc;
+    double *s_gs = s_xg + ni;
     const int tid = threadIdx.x;
     for (int i = tid; i < ni; i += BLOCK) {
-        s_xg[i] = a.c.xg[i]; s_dudz[i] = a.c.dudz[i]; s_dvdz[i] = a.c.dvdz[i];
-        if (i < ni - 1) { s_slu[i] = a.c.slu[i]; s_slv[i] = a.c.slv[i]; }
+        s_xg[i] = a.c.xg[i];
+        const bool in = i < ni - 1;
+        s_sh[i] = make_double4(a.c.dudz[i], in ? a.c.slu[i] : 0.0, a.c.dvdz[i], in ? a.c.slv[i] : 0.0);
     }
     if (NEED_RHO)
         for (int i = tid; i < nc; i += BLOCK) {
-            s_gs[i] = a.c.grids[i]; s_rho[i] = a.c.rhobar[i];
-            if (i < nc - 1) s_slrho[i] = a.c.slrho[i];
+            s_gs[i] = a.c.grids[i];
+            s_rho2[i] = make_double2(a.c.rhobar[i], (i < nc - 1) ? a.c.slrho[i] : 0.0);
         }
     __syncthreads();
 
@@ -529,12 +645,12 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
         const long long i0 = base + 2 * tid;
         const bool v0 = i0 < a.n, v1 = i0 + 1 < a.n;
         double rr[2], mm[2], kk[2], ll[2], dens[2], ff[2], pvf[2];
-        load2(a.r.rr, i0, v0, v1, rr, 0.0);
-        load2(a.r.mm, i0, v0, v1, mm, 1.0);
-        load2(a.r.kk, i0, v0, v1, kk, 1.0);
-        load2(a.r.ll, i0, v0, v1, ll, 0.0);
-        if (FVEC) load2(a.r.fray, i0, v0, v1, ff, 0.0);
-        if (NEED_RHO) { load2(a.r.dens, i0, v0, v1, dens, 0.0); load2(a.r.pvf, i0, v0, v1, pvf, 1.0); }
+        load2(a.r.rr, i0, rr);
+        load2(a.r.mm, i0, mm);
+        load2(a.r.kk, i0, kk);
+        load2(a.r.ll, i0, ll);
+        if (FVEC) load2(a.r.fray, i0, ff);
+        if (NEED_RHO) { load2(a.r.dens, i0, dens); load2(a.r.pvf, i0, pvf); }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const double f = FVEC ? ff[r] : a.f_uni;
@@ -549,18 +665,18 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
                 const double om = sqrt((a.bvf2 * kh2 + f2 * m2) / vk2);
                 const double cgr = -mm[r] * (om * om - f2) / om / vk2;
                 const double st_rr = .5 * (cgr + cgr);
-                int mode;
-                const int j = interp_locate(rr[r], s_xg, ni, a.xg0, a.inv_dzg, mode);
-                const double gu = interp_eval(rr[r], j, mode, s_xg, s_dudz, s_slu);
-                const double gv = interp_eval(rr[r], j, mode, s_xg, s_dvdz, s_slv);
+                const Bracket bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
+                const double4 sh = s_sh[bk.j];
+                const double gu = interp_eval(rr[r], bk, sh.x, sh.y);
+                const double gv = interp_eval(rr[r], bk, sh.z, sh.w);
                 const double st_mm = (kk[r] * 0.0 + ll[r] * 0.0) - (kk[r] * gu + ll[r] * gv);
                 double st_dens = 0.0;
                 if (SAT) {
                     const double rr_f = rr[r] + st_rr * a.dt;
                     const double mm_f = mm[r] + st_mm * a.dt;
-                    int md;
-                    const int jr = interp_locate(rr_f, s_gs, nc, a.gs0, a.inv_dzs, md);
-                    const double rho_f = interp_eval(rr_f, jr, md, s_gs, s_rho, s_slrho);
+                    const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+                    const double2 rh = s_rho2[br.j];                                   // {rhobar, slope}
+                    const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);   // :595
                     const double omh = a.same_f ? om : sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);
                     const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
                     if (maxd < dens[r] * pvf[r]) st_dens = (maxd - dens[r]) / a.dt;
@@ -582,18 +698,18 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
                 const double mm_st = (mm[r] - mm_old) / a.dt;
                 const double rr_f = rr_old + rr_st * a.dt;
                 const double mm_f = mm_old + mm_st * a.dt;
-                int md;
-                const int jr = interp_locate(rr_f, s_gs, nc, a.gs0, a.inv_dzs, md);
-                const double rho_f = interp_eval(rr_f, jr, md, s_gs, s_rho, s_slrho);
+                const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+                const double2 rh = s_rho2[br.j];                                   // {rhobar, slope}
+                const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);   // :595
                 const double m02 = mm_old * mm_old;
                 const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m02) / (kh2 + m02));
                 const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
                 if (maxd < dens[r] * pvf[r]) dens[r] = maxd;
             }
         }
-        store2(a.r.rr, i0, v0, v1, rr);
-        store2(a.r.mm, i0, v0, v1, mm);
-        if (NEED_RHO) store2(a.r.dens, i0, v0, v1, dens);
+        store2(a.r.rr, i0, rr);
+        store2(a.r.mm, i0, mm);
+        if (NEED_RHO) store2(a.r.dens, i0, dens);
     }
 }
 
@@ -618,7 +734,7 @@ struct ProjArgs {
 template <int NP, bool FVEC, bool EXPL>
 __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int nG = a.nG, ncp = nG - 1;
     double *s_G = lds;
     double *s_rows = s_G + nG;
@@ -628,6 +744,7 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
     for (int i = tid; i < WAVES * NP * ncp; i += BLOCK) s_rows[i] = 0.0;
     __syncthreads();
     int wmin = INT_MAX, wmax = INT_MIN;
+    double acc0[NP][1] = {};                                 // unused (NH = 0: LDS accumulation)
     const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = (tile0 + t) * (long long)TILE;
@@ -638,17 +755,17 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
         double kk[2], ll[2], dens[2], vol[2], ff[2], lo[2], up[2], mmid[2];
         if (EXPL) {
             double mlo[2], mup[2], dkk[2], dll[2], dmm[2];
-            load2(a.e.dens, i0, v0, v1, dens, 0.0);
-            load2(a.e.lo, i0, v0, v1, lo, 0.0);
-            load2(a.e.up, i0, v0, v1, up, 0.0);
-            load2(a.e.kk, i0, v0, v1, kk, 1.0);
-            load2(a.e.ll, i0, v0, v1, ll, 0.0);
-            load2(a.e.mlo, i0, v0, v1, mlo, 1.0);
-            load2(a.e.mup, i0, v0, v1, mup, 1.0);
-            load2(a.e.dkk, i0, v0, v1, dkk, 0.0);
-            load2(a.e.dll, i0, v0, v1, dll, 0.0);
-            load2(a.e.dmm, i0, v0, v1, dmm, 0.0);
-            load2(a.e.fray, i0, v0, v1, ff, 0.0);
+            load2(a.e.dens, i0, dens);
+            load2(a.e.lo, i0, lo);
+            load2(a.e.up, i0, up);
+            load2(a.e.kk, i0, kk);
+            load2(a.e.ll, i0, ll);
+            load2(a.e.mlo, i0, mlo);
+            load2(a.e.mup, i0, mup);
+            load2(a.e.dkk, i0, dkk);
+            load2(a.e.dll, i0, dll);
+            load2(a.e.dmm, i0, dmm);
+            load2(a.e.fray, i0, ff);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 vol[r] = fabs(dkk[r] * dll[r] * dmm[r]);              // :137
@@ -656,15 +773,15 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
             }
         } else {
             double rr[2], mm[2], drr[2], dmm[2];
-            load2(a.r.rr, i0, v0, v1, rr, 0.0);
-            load2(a.r.mm, i0, v0, v1, mm, 1.0);
-            load2(a.r.kk, i0, v0, v1, kk, 1.0);
-            load2(a.r.ll, i0, v0, v1, ll, 0.0);
-            load2(a.r.dens, i0, v0, v1, dens, 0.0);
-            load2(a.r.drr, i0, v0, v1, drr, 1.0);
-            load2(a.r.dmm, i0, v0, v1, dmm, 0.0);
-            load2(a.r.vol, i0, v0, v1, vol, 0.0);
-            if (FVEC) load2(a.r.fray, i0, v0, v1, ff, 0.0);
+            load2(a.r.rr, i0, rr);
+            load2(a.r.mm, i0, mm);
+            load2(a.r.kk, i0, kk);
+            load2(a.r.ll, i0, ll);
+            load2(a.r.dens, i0, dens);
+            load2(a.r.drr, i0, drr);
+            load2(a.r.dmm, i0, dmm);
+            load2(a.r.vol, i0, vol);
+            if (FVEC) load2(a.r.fray, i0, ff);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 lo[r] = rr[r] - .5 * drr[r];                          // :655 / raytracer.py:200-201
@@ -683,8 +800,8 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
             if (NP == 2) { pay[0][r] = cgr * kk[r] * dens[r]; pay[NP - 1][r] = cgr * ll[r] * dens[r]; }   // :148-149
             else pay[0][r] = (a.var == 1) ? cgr * dens[r] : dens[r];                     // :167, :184
         }
-        deposit_tile<NP>(lo, up, nlo, nup, vol, pay, s_G, a.dz, a.cdz, a.mk_ok,
-                         s_rows + wave * NP * ncp, ncp, lane, wmin, wmax);
+        deposit_tile<NP, 0>(lo, up, nlo, nup, vol, pay, s_G, a.dz, a.cdz, a.mk_ok,
+                            s_rows + wave * NP * ncp, ncp, lane, wmin, wmax, acc0);
     }
     flush_rows<NP>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
 }
@@ -693,7 +810,7 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
 struct SatArgs {
     long long n;
     int nc, direct;
-    double dt, bvf2, f0sq, sat_c, gs0, inv_dzs;
+    double dt, bvf2, f0sq, sat_c, gs0, gs_last, inv_dzs;
     const double *dens, *rr, *rr_st, *drr, *drr_st, *kk, *ll, *mm, *mm_st, *dkk, *dll, *area;
     const double *grids, *rhobar, *slrho;
     double *out;
@@ -706,9 +823,8 @@ __global__ void __launch_bounds__(BLOCK) k_saturation(const SatArgs a)
     const double drr_f = a.drr[i] + a.drr_st[i] * a.dt;              // :592
     const double mm_f = a.mm[i] + a.mm_st[i] * a.dt;                 // :593
     const double dmm_f = a.area[i] / drr_f;                          // :594
-    int md;
-    const int j = interp_locate(rr_f, a.grids, a.nc, a.gs0, a.inv_dzs, md);
-    const double rho_f = interp_eval(rr_f, j, md, a.grids, a.rhobar, a.slrho);   // :595
+    const Bracket br = interp_locate(rr_f, a.grids, a.nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+    const double rho_f = interp_eval(rr_f, br, a.rhobar[br.j], a.slrho[min(br.j, a.nc - 2)]);   // :595
     const double kh2 = a.kk[i] * a.kk[i] + a.ll[i] * a.ll[i];
     const double m2 = a.mm[i] * a.mm[i];
     const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m2) / (kh2 + m2));          // :597
@@ -720,7 +836,14 @@ __global__ void __launch_bounds__(BLOCK) k_saturation(const SatArgs a)
     else a.out[i] = hit ? (maxd - d) / a.dt : 0.0;                   // :612-615
 }
 
-// ------------------------------------------------------------------ upload helper
+// ------------------------------------------------------------------ upload helpers
+// inert padding rays [from, to) so that whole-tile vector accesses stay in initialised memory
+__global__ void k_fill_range(double *p, long long from, long long to, double v)
+{
+    const long long i = from + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < to) p[i] = v;
+}
+
 // vol = |dkk*dll*dmm| (:137) and pvf = dkk*dll*(rr_mm_area/drr) (:594, :599 with
 // drr_final = drr + 0*dt) once per upload.
 __global__ void k_prepare(long long n, const double *dkk, const double *dll, const double *area,

@@ -5,8 +5,12 @@ condition (`raytracer.py:71-117`): the same launch layer 0-15 km and wave-action
 formula (`raytracer.py:112-117`), tiled deterministically (no RNG) in height,
 vertical wavenumber and azimuth so that every box builds the identical spectrum.
 
-Ray order is z-major: index = (iz * Nm + im) * Nd + id, so neighbouring lanes
-of a wavefront share a flux level, and a contiguous index range is a shard.
+Ray order is z-major, then azimuth, then vertical wavenumber:
+index = (iz * Nd + id) * Nm + im.  Neighbouring rays (the lanes of a wavefront)
+share the launch height and the propagation direction and differ only slightly
+in m, so they keep sharing a flux level as they propagate (rays of opposite
+azimuth get opposite-signed dm/dt and drift apart, so azimuth must not be the
+fastest index); a contiguous index range is a shard.
 """
 import numpy as np
 
@@ -30,8 +34,8 @@ def gaussian_spectrum(nray, grids, rhobar, alpha=0.01, bvf=0.01, phi0=0.0,
     nz, nm, nd = spectrum_shape(nray, nz, nd)
     stop = nray if stop is None else stop
     idx = np.arange(start, stop, dtype=np.int64)
-    i_d = idx % nd
-    i_m = (idx // nd) % nm
+    i_m = idx % nm
+    i_d = (idx // nm) % nd
     i_z = idx // (nd * nm)
 
     dz_ray = (z_max - z_min) / nz                      # cf. raytracer.py:88-90

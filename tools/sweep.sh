@@ -1,8 +1,10 @@
 #!/bin/bash
-# GPU box: sweep launch geometry / prefetch for the coupled bench; one JSON summary line each
+# GPU box: sweep launch geometry / prefetch for the coupled bench; one summary line each
+# usage: tools/sweep.sh "<PF list>" "<BPC list>" [bench args]
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
-for PF in 0 1; do for BPC in 2 4 6 8 16; do
+PFS=${1:-"0 1"}; BPCS=${2:-"2 4 8"}; shift; shift
+for PF in $PFS; do for BPC in $BPCS; do
   MSGW_PREFETCH=$PF MSGW_BLOCKS_PER_CU=$BPC timeout -k 10 120 python bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
