@@ -105,8 +105,8 @@ __global__ void __launch_bounds__(COL_BLOCK) k_column(const ColArgs a)
                 for (int i = tid; i < 2 * ng; i += COL_BLOCK) a.out_flux[i] = s_F[i];
             for (int j = tid; j < nc; j += COL_BLOCK) {
                 double du, dv;
-                column_tendency(j, ng, a.f0, a.dzg, a.fixed_background, s_F, a.rhobar, a.pg,
-                                a.in.uu[j], a.in.vv[j], du, dv);
+                column_tendency(j, ng, a.f0, a.dzg, a.fixed_background, s_F, a.rhobar[j], a.pg[j],
+                                a.pg[nc + j], a.in.uu[j], a.in.vv[j], du, dv);
                 if (a.out_du) a.out_du[j] = du;
                 if (a.out_dv) a.out_dv[j] = dv;
             }
@@ -154,12 +154,12 @@ __global__ void __launch_bounds__(COL_BLOCK) k_flux_reduce1(const Red1Args a)
         const int b0 = (int)((long long)seg * nr / a.nseg), b1 = (int)((long long)(seg + 1) * nr / a.nseg);
         const double *src = a.partial + (size_t)r0 * a.ncols + col;
         double acc = 0.0;
-        for (int b = b0; b < b1; b += 8) {
-            double v[8];
+        for (int b = b0; b < b1; b += 16) {                  // 16 loads in flight per thread
+            double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(b + u, b1 - 1) * a.ncols];
+            for (int u = 0; u < 16; ++u) v[u] = src[(size_t)min(b + u, b1 - 1) * a.ncols];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int bb = min(b + u, b1 - 1);
                 const bool in = (b + u < b1) && (c >= s_rng[2 * bb]) && (c < s_rng[2 * bb + 1]);
                 acc = acc + (in ? v[u] : 0.0);

@@ -26,16 +26,15 @@ __device__ __forceinline__ void column_flux_ends(int tid, int ng, double *s_F)
 
 // du_dt, dv_dt (:523-558) of level j from the interface flux.
 __device__ __forceinline__ void column_tendency(int j, int ng, double f0, double dzg, int fixed_bg,
-                                                const double *s_F, const double *rhobar,
-                                                const double *pg, double u, double v,
+                                                const double *s_F, double rho, double pg0,
+                                                double pg1, double u, double v,
                                                 double &du, double &dv)
 {
-    const int nc = ng - 1;
     const double gx = (s_F[j + 1] - s_F[j]) / dzg;                       // :663
     const double gy = (s_F[ng + j + 1] - s_F[ng + j]) / dzg;
-    const double rinv = 1.0 / rhobar[j];                                 // rhobar**-1
-    du = f0 * v - rinv * (pg[j] + gx);                                   // :537
-    dv = -f0 * u - rinv * (pg[nc + j] + gy);                             // :556
+    const double rinv = 1.0 / rho;                                       // rhobar**-1
+    du = f0 * v - rinv * (pg0 + gx);                                     // :537
+    dv = -f0 * u - rinv * (pg1 + gy);                                    // :556
     if (fixed_bg) { du = 0.0; dv = 0.0; }
 }
 
@@ -69,7 +68,7 @@ __device__ __forceinline__ void column_stage_all(int stage, int tid, int nthr, i
     for (int j = tid; j < nc; j += nthr) {
         const double u = in.uu[j], v = in.vv[j];
         double du, dv, un, vn, qu, qv;
-        column_tendency(j, ng, f0, dzg, fixed_bg, s_F, rhobar, pg, u, v, du, dv);
+        column_tendency(j, ng, f0, dzg, fixed_bg, s_F, rhobar[j], pg[j], pg[nc + j], u, v, du, dv);
         const double quo = (stage == 0) ? 0.0 : in.q_uu[j], qvo = (stage == 0) ? 0.0 : in.q_vv[j];
         column_rk(stage, dt, du, dv, u, v, quo, qvo, un, vn, qu, qv);
         s_u[j] = un; s_v[j] = vn;

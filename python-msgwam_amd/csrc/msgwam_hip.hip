@@ -103,6 +103,12 @@ struct msgw_ctx {
     int ranges_cap = 0;
     double *row2 = nullptr;          // [RED1_GROUPS][ncols] second-level flux rows
     size_t row2_elems = 0;
+    // in-kernel group reduction of the RK-stage kernels
+    double *grp_part = nullptr, *grp_rows = nullptr;
+    unsigned int *grp_cnt = nullptr;
+    size_t grp_part_elems = 0;
+    int grp_size = 1, ngroups = 1, row_stride = 0;
+    bool groupred = false;           // set while enqueueing fused stages
 
     // graph
     int graph_steps = 0;
@@ -167,7 +173,7 @@ size_t col_lds_bytes(int ng, int nseg, int ncols, int nblocks)
     return sizeof(double) * (size_t)(2 * ng + 2 * (ng - 1) + 2 * (ng - 2) + (size_t)nseg * ncols) +
            sizeof(int) * 2 * (size_t)nblocks + 16;
 }
-constexpr int RED1_GROUPS = 32;      // first-level reduce workgroups
+constexpr int RED1_GROUPS = FUSE_ROWS;      // first-level reduce workgroups
 constexpr int RED1_MIN_ROWS = 128;   // below this the single-workgroup column kernel reads the rows itself
 
 int pick_nseg(int ncols)
@@ -239,6 +245,30 @@ int ensure_partial(msgw_ctx *c, int blocks, size_t row_elems)
     return MSGW_OK;
 }
 
+// buffers of the in-kernel group reduction for the current launch geometry
+int ensure_groups(msgw_ctx *c)
+{
+    const int ncols = 2 * (c->ng - 2);
+    c->row_stride = ((ncols + 15) / 16) * 16;                  // 128-B multiple: no line shared by two rows
+    c->grp_size = (c->blocks + FUSE_ROWS - 1) / FUSE_ROWS;
+    c->ngroups = (c->blocks + c->grp_size - 1) / c->grp_size;
+    const size_t need = (size_t)c->blocks * c->row_stride;
+    if (need > c->grp_part_elems) {
+        drop_graph(c);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->grp_part) HIPCHK(c, hipFree(c->grp_part));
+        c->grp_part = nullptr;
+        HIPCHK(c, hipMalloc(&c->grp_part, need * sizeof(double)));
+        c->grp_part_elems = need;
+    }
+    if (!c->grp_rows) {
+        HIPCHK(c, hipMalloc(&c->grp_rows, sizeof(double) * (size_t)FUSE_ROWS * 2 * (c->ng - 2)));
+        HIPCHK(c, hipMalloc(&c->grp_cnt, sizeof(unsigned int) * 64));
+    }
+    HIPCHK(c, hipMemsetAsync(c->grp_cnt, 0, sizeof(unsigned int) * 64, c->stream));
+    return MSGW_OK;
+}
+
 // First level of the flux reduction (many workgroup rows -> RED1_GROUPS dense rows);
 // rewrites `a` so that the column kernel reads the second-level rows.
 int reduce_level1(msgw_ctx *c, ColArgs &a, bool force = false)
@@ -283,6 +313,8 @@ StageArgs make_stage_args(msgw_ctx *c, double dt, unsigned flags)
     a.ranges = c->ranges;
     a.col_pending = 0;
     a.pg = c->pg; a.f0 = c->f0; a.dzg = c->dzg;
+    a.grp_size = c->grp_size; a.row_stride = c->row_stride;
+    a.grp_part = c->grp_part; a.grp_rows = c->grp_rows; a.grp_cnt = c->grp_cnt;
     return a;
 }
 
@@ -341,6 +373,8 @@ int launch_stage_t(msgw_ctx *c, const StageArgs &a)
 {
     if (c->ng - 2 > 128)   // tall columns: per-level sums stay in LDS (NH = 0)
         return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false, 0>, stage_lds_bytes(c->ng), a);
+    if (c->groupred && DEPOSIT && STAGE != 3)   // fused chain: first-level flux reduction inside the kernel
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false, 2, (DEPOSIT && STAGE != 3)>, stage_lds_bytes(c->ng), a);
     if (c->prefetch && c->tiles_per_block > 1 && STAGE != 3)
         return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, (STAGE != 3), 2>, stage_lds_bytes(c->ng), a);
     return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false, 2>, stage_lds_bytes(c->ng), a);
@@ -444,6 +478,19 @@ int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_k
     }
     const ColIn in_set[2] = {ColIn{c->uu, c->vv, c->q_uu, c->q_vv}, ColIn{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
     const ColOut out_set[2] = {ColOut{c->uu, c->vv, c->q_uu, c->q_vv}, ColOut{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
+    const bool can_fuse = (2 * (c->ng - 2) <= BLOCK) && (c->ng - 1 <= BLOCK);   // one thread per column/level
+    if (!can_fuse) {                   // tall columns: standalone column kernel after every stage
+        const ColArgs ca = make_col_args(c, dt, flags);
+        for (int step = 0; step < count; ++step) {
+            if (int rc = timed([&] { return launch_stage<0>(c, sa, mode); })) return rc;
+            if (int rc = column_stage<0>(c, ca)) return rc;
+            if (int rc = timed([&] { return launch_stage<1>(c, sa, mode); })) return rc;
+            if (int rc = column_stage<1>(c, ca)) return rc;
+            if (int rc = timed([&] { return launch_stage<2>(c, sa, mode); })) return rc;
+            if (int rc = column_stage<2>(c, ca)) return rc;
+        }
+        return MSGW_OK;
+    }
     int cur = 0;                       // set that holds the column BEFORE the pending update
     bool pending = false;
     int pend_stage = 0;
@@ -457,13 +504,15 @@ int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_k
             sa.cin = in_set[cur];
             sa.cout = out_set[cur ^ 1];
             int rc = MSGW_OK;
+            c->groupred = true;
             if (s == 0) rc = timed([&] { return launch_stage<0>(c, sa, mode); });
             else if (s == 1) rc = timed([&] { return launch_stage<1>(c, sa, mode); });
             else rc = timed([&] { return launch_stage<2>(c, sa, mode); });
+            c->groupred = false;
             if (rc) return rc;
             if (pending) cur ^= 1;     // workgroup 0 has published the updated column there
             rows = make_col_args(c, dt, flags);
-            if ((rc = reduce_level1(c, rows, true))) return rc;            // -> dense rows in row2
+            rows.partial = c->grp_rows; rows.ranges = nullptr; rows.nblocks = c->ngroups;   // dense group rows
             if (c->nranks > 1) {       // local rows -> one flux row, summed over the ranks
                 if ((rc = launch_column_t<4, COL_REDUCE>(c, rows))) return rc;
                 if ((rc = allreduce_flux(c))) return rc;
@@ -476,7 +525,7 @@ int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_k
     // the last update of the batch: standalone, from set `cur` into the canonical set
     rows.in = in_set[cur];
     rows.out = out_set[0];
-    rows.nseg = pick_nseg(rows.npay * rows.ncp);
+    rows.nseg = 1;                     // same (sequential) row order as the fused prologue: bitwise equal
     return launch_column_t<2, COL_REDUCE | COL_UPDATE>(c, rows);
 }
 
@@ -562,6 +611,9 @@ int msgw_destroy(msgw_ctx *c)
     if (c->partial) (void)hipFree(c->partial);
     if (c->ranges) (void)hipFree(c->ranges);
     if (c->row2) (void)hipFree(c->row2);
+    if (c->grp_part) (void)hipFree(c->grp_part);
+    if (c->grp_rows) (void)hipFree(c->grp_rows);
+    if (c->grp_cnt) (void)hipFree(c->grp_cnt);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -648,6 +700,7 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
     c->n = n;
     geometry(c, n);
     if (int rc = ensure_partial(c, c->blocks, (size_t)2 * (c->ng - 2))) return rc;
+    if (int rc = ensure_groups(c)) return rc;
     c->have_rays = true;
     c->cnt.nray = n;
     c->cnt.blocks = c->blocks;
@@ -667,6 +720,7 @@ int msgw_set_tuning(msgw_ctx *c, int blocks_per_cu, int graph_steps)
     if (c->have_rays) {
         geometry(c, c->n);
         if (int rc = ensure_partial(c, c->blocks, (size_t)2 * (c->ng - 2))) return rc;
+        if (int rc = ensure_groups(c)) return rc;
         c->cnt.blocks = c->blocks;
     }
     return MSGW_OK;

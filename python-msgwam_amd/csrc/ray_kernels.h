@@ -17,6 +17,7 @@ constexpr int RPT = 2;               // rays per lane -> 16-B global accesses
 constexpr int TILE = BLOCK * RPT;    // rays per workgroup iteration
 constexpr int SPAN_MAX = 8;          // widest per-wave level span on the shuffle path
 constexpr int COL_BLOCK = 1024;      // the column kernel is one workgroup
+constexpr int FUSE_ROWS = 16;        // most dense flux rows the fused prologue adds up (= reduce-1 groups)
 
 struct RayPtrs {
     double *dens, *rr, *mm;                        // evolving slots 0, 3, 7
@@ -55,6 +56,14 @@ struct StageArgs {
     ColPtrs c;
     double *partial;      // [blocks][2][ng-2] per-workgroup flux rows
     int *ranges;          // [blocks][2] touched level range of each row
+    // In-kernel first-level flux reduction (GROUPRED kernels): workgroups [g*grp_size, ...) publish
+    // dense rows to grp_part (write-through), take a ticket on grp_cnt[g]; the last arriver adds
+    // the group's rows in row order into grp_rows[g].
+    int grp_size;             // workgroups per group
+    int row_stride;           // doubles per published row (multiple of 16: rows never share a 128-B line)
+    double *grp_part;         // [blocks][row_stride]
+    double *grp_rows;         // [ngroups][2*(ng-2)] dense group sums
+    unsigned int *grp_cnt;    // [ngroups] arrival tickets (zero between launches)
     // Pending mean-flow update of the PREVIOUS RK stage, applied in this kernel's prologue by
     // every workgroup in LDS (workgroup 0 also publishes the new column to cout):
     int col_pending;      // 0: shear tables are read from c.dudz..; 1: apply the update below first
@@ -337,6 +346,74 @@ __device__ __forceinline__ void flush_rows(const double *rows, int ncp, int *s_r
     if (tid == 0) { ranges[2 * blockIdx.x] = bmin; ranges[2 * blockIdx.x + 1] = bmax; }
 }
 
+// Group variant of flush_rows (used by the RK-stage kernels): the workgroup's dense row is
+// published with write-through (sc1) 8-byte stores, every storing wave drains its stores, one
+// lane takes a ticket on the group's counter; the workgroup that draws the last ticket acquires
+// (agent scope) and adds the group's rows in row order -- independent of arrival order, so the
+// result is bitwise reproducible.  Protocol: cdna_hip_programming.md Guideline 16 / split-K
+// recipe (sc1 payload + drained vmcnt + barrier + relaxed agent fetch_add; consumer acquire).
+template <int NP>
+__device__ __forceinline__ void flush_rows_group(const double *rows, int ncp, int *s_flag, double *s_scr,
+                                                 int tid, const StageArgs &a)
+{
+    typedef unsigned long long u64;
+    const int ncols = NP * ncp;
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int g = b / a.grp_size, r0 = g * a.grp_size, r1 = min(nb, r0 + a.grp_size);
+    __syncthreads();                                          // all waves' rows complete in LDS
+    double *mine = a.grp_part + (size_t)b * a.row_stride;
+    for (int col = tid; col < ncols; col += BLOCK) {
+        double acc = rows[col];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) acc = acc + rows[w * ncols + col];
+        __hip_atomic_store(reinterpret_cast<u64 *>(mine + col), (u64)__double_as_longlong(acc),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // sc1 store
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(a.grp_cnt + g, 1u, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+    // last arriver: two interleaved row sets (even / odd rows of the group), two columns per thread
+    const int nc2 = (ncols + 1) / 2;                          // 16-B column pairs
+    const int set = tid / nc2, c2 = tid - set * nc2;
+    double2 acc2 = make_double2(0.0, 0.0);
+    if (set < 2) {
+        const double *src = a.grp_part + 2 * c2;
+        for (int r = r0 + set; r < r1; r += 32) {             // 16 rows of this set per batch
+            double2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                v[u] = *reinterpret_cast<const double2 *>(src + (size_t)min(r + 2 * u, r1 - 1) * a.row_stride);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool in = (r + 2 * u) < r1;
+                acc2.x = acc2.x + (in ? v[u].x : 0.0);
+                acc2.y = acc2.y + (in ? v[u].y : 0.0);
+            }
+        }
+        if (set == 1) { s_scr[2 * c2] = acc2.x; s_scr[2 * c2 + 1] = acc2.y; }
+    }
+    __syncthreads();
+    if (set == 0) {
+        double *dst = a.grp_rows + (size_t)g * ncols;
+        const double x = acc2.x + s_scr[2 * c2], y = acc2.y + s_scr[2 * c2 + 1];
+        if (2 * c2 < ncols) dst[2 * c2] = x;
+        if (2 * c2 + 1 < ncols) dst[2 * c2 + 1] = y;
+    }
+    if (tid == 0)                                             // re-arm the ticket for the next launch
+        __hip_atomic_store(a.grp_cnt + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------ dispersion
 // omega :383 and cg_rr :445-448 sharing sub-expressions (numpy recomputes the
 // identical values; sharing them is bit-neutral).
@@ -404,7 +481,8 @@ __device__ __forceinline__ void load_tile(TileRegs &t, const StageArgs &a, long 
 // PREFETCH: keep a second register set and issue tile t+1's loads before tile t's math
 // (costs ~50 VGPRs, i.e. occupancy); without it a workgroup relies on the other resident
 // workgroups to cover its load latency.  Picked per launch by the host (MSGW_PREFETCH).
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool PREFETCH, int NH = 2>
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool PREFETCH, int NH = 2,
+          bool GROUPRED = false>
 __global__ void __launch_bounds__(BLOCK, PREFETCH ? 4 : 1) k_ray_stage(const StageArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -424,32 +502,47 @@ __global__ void __launch_bounds__(BLOCK, PREFETCH ? 4 : 1) k_ray_stage(const Sta
     const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
 
     MSGW_STAMP_AT(0);
-    // the first tile's ray loads go out before the column is staged: both latencies overlap
+    // Load order matters (vmcnt retires in order): first the handful of loads of the pending
+    // mean-flow update, THEN the first tile's ray loads, so that the column math below runs
+    // while the ray data is still in flight.  (Host guarantees 2*ncp <= BLOCK and nc <= BLOCK
+    // and col_nrows <= FUSE_ROWS whenever col_pending is set.)
+    const bool fuse = DEPOSIT && a.col_pending;
+    const int ncols = 2 * ncp;
+    double prow[FUSE_ROWS];
+    double c_u = 0, c_v = 0, c_qu = 0, c_qv = 0, c_rho = 1, c_pg0 = 0, c_pg1 = 0;
+    if (fuse) {
+        const int col = min(tid, ncols - 1), jc = min(tid, nc - 1);
+#pragma unroll
+        for (int u = 0; u < FUSE_ROWS; ++u)
+            prow[u] = a.col_rows[(size_t)min(u, a.col_nrows - 1) * ncols + col];
+        c_u = a.cin.uu[jc]; c_v = a.cin.vv[jc];
+        c_qu = a.cin.q_uu[jc]; c_qv = a.cin.q_vv[jc];
+        c_rho = a.c.rhobar[jc]; c_pg0 = a.pg[jc]; c_pg1 = a.pg[nc + jc];
+    }
     TileRegs cur, nxt;
     load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, tile0 * (long long)TILE, tid);
 
     for (int i = tid; i < ni; i += BLOCK) s_xg[i] = a.c.xg[i];
-    if (DEPOSIT && a.col_pending) {
-        // (1) finish the flux reduction: add the dense rows in row order (8 loads in flight)
-        const int ncols = 2 * ncp;
-        for (int col = tid; col < ncols; col += BLOCK) {
+    if (fuse) {
+        // (1) finish the flux reduction: add the dense rows in row order
+        if (tid < ncols) {
             double tot = 0.0;
-            for (int r0 = 0; r0 < a.col_nrows; r0 += 8) {
-                double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = a.col_rows[(size_t)min(r0 + u, a.col_nrows - 1) * ncols + col];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) tot = tot + ((r0 + u < a.col_nrows) ? v[u] : 0.0);
-            }
-            const int p = col / ncp, c = col - p * ncp;
+            for (int u = 0; u < FUSE_ROWS; ++u) tot = tot + ((u < a.col_nrows) ? prow[u] : 0.0);
+            const int p = tid / ncp, c = tid - p * ncp;
             s_F[p * ng + 1 + c] = tot;                       // pm_flux[:, 1:-1]  (:654)
         }
         __syncthreads();
         column_flux_ends(tid, ng, s_F);
         __syncthreads();
         // (2) RK stage of uu, vv (:665-666, :693-698); workgroup 0 publishes the new column
-        column_stage_all(a.col_stage, tid, BLOCK, ng, a.dt, a.f0, a.dzg, 0, s_F, a.c.rhobar, a.pg,
-                         a.cin, a.cout, blockIdx.x == 0, s_u, s_v);
+        if (tid < nc) {
+            double du, dv, un, vn, qu, qv;
+            column_tendency(tid, ng, a.f0, a.dzg, 0, s_F, c_rho, c_pg0, c_pg1, c_u, c_v, du, dv);
+            column_rk(a.col_stage, a.dt, du, dv, c_u, c_v, c_qu, c_qv, un, vn, qu, qv);
+            s_u[tid] = un; s_v[tid] = vn;
+            if (blockIdx.x == 0) { a.cout.uu[tid] = un; a.cout.vv[tid] = vn; a.cout.q_uu[tid] = qu; a.cout.q_vv[tid] = qv; }
+        }
         __syncthreads();
         // (3) shear + np.interp slopes straight into the packed LDS table
         column_shear(tid, BLOCK, ng, a.dzg, s_u, s_v, s_du, s_dv);
@@ -606,7 +699,8 @@ __global__ void __launch_bounds__(BLOCK, PREFETCH ? 4 : 1) k_ray_stage(const Sta
     }
     if (DEPOSIT) {
         flush_acc<2, NH>(s_rows + wave * 2 * ncp, ncp, lane, acc);
-        flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
+        if (GROUPRED) flush_rows_group<2>(s_rows, ncp, s_rng, lds /* interp tables are dead by now */, tid, a);
+        else flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
     }
     MSGW_STAMP_AT(6);
 }
