@@ -202,12 +202,14 @@ def saturation(setup, dt, dens, rr_center, rr_center_st, drr, drr_st, kk, ll,
 # --------------------------------------------------------------------------
 # a-2 / a-6  right-hand side  (HPROP_GLOBAL = False branch, scalar bvf)
 # --------------------------------------------------------------------------
-def rhs(setup, dt, state, loop=False, fixed_background=False, return_flux=False):
+def rhs(setup, dt, state, loop=False, fixed_background=False, return_flux=False, flux_reduce=None):
     """lib/libprop.py:618-676 with HPROP_GLOBAL=False (raytracer.py:38).
 
     state = [dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv].
     `fixed_background=True` is the rhs-hook variant of BASELINE config 1/2:
     identical tendencies with slots 9, 10 zeroed.
+    `flux_reduce` (multi-rank tests only): callable applied to this rank's
+    (2, ngrid-2) projection, e.g. a gloo all-reduce over ray shards.
     """
     dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = state
     bvf = setup.bvf
@@ -230,9 +232,12 @@ def rhs(setup, dt, state, loop=False, fixed_background=False, return_flux=False)
 
     grid, grids = setup.grid, setup.grids
     pm_flux = np.zeros((2, len(grid)))                   # :653
-    pm_flux[:, 1:-1] = wave_projection(                  # :654-658
+    proj = wave_projection(                              # :654-658
         dens, rr - .5 * drr, rr + .5 * drr, kk, ll, mm - .5 * dmm, mm + .5 * dmm,
         phi, setup.dkk, setup.dll, dmm, grids, bvf, var=0, loop=loop)
+    if flux_reduce is not None:
+        proj = flux_reduce(proj)
+    pm_flux[:, 1:-1] = proj
     pm_flux[:, 0] = pm_flux[:, 1]
     pm_flux[:, -1] = pm_flux[:, -2]
     dz = np.diff(grid[:2])[0]
@@ -252,11 +257,11 @@ def rhs(setup, dt, state, loop=False, fixed_background=False, return_flux=False)
     return out
 
 
-def rk3(setup, dt, state, loop=False, fixed_background=False):
+def rk3(setup, dt, state, loop=False, fixed_background=False, flux_reduce=None):
     """lib/libprop.py:680-700, slot by slot (so nray == ngrid-1 cannot collapse
     the object array as it does in the reference)."""
     var = [np.asarray(s, dtype=np.float64) for s in state]
-    f = lambda v: rhs(setup, dt, v, loop=loop, fixed_background=fixed_background)
+    f = lambda v: rhs(setup, dt, v, loop=loop, fixed_background=fixed_background, flux_reduce=flux_reduce)
     qq = [dt * r for r in f(var)]
     var = [v + q / 3 for v, q in zip(var, qq)]
     qq = [dt * r - 5 / 9 * q for r, q in zip(f(var), qq)]

@@ -1,0 +1,123 @@
+"""-m gpu: the drop-in module surface (msgwam_amd.libprop) and the headless driver
+against golden vectors from the real reference."""
+import numpy as np
+import pytest
+
+from helpers import STATE_KEYS, load, state_from, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _configure_from(d, lprop, sat=None):
+    lprop.HPROP_GLOBAL = False
+    lprop.set_model_setup(bvf=float(d["bvf"]), rhs=lprop.rhs_default, boussinesq=False, sig_rr=10000, u0=4,
+                          rr0=40000, rr1=40000, phi0=float(d["phi0"]), kappa=float(d["kappa"]),
+                          saturate_online=bool(int(d["saturate_online"])) if sat is None else sat,
+                          hh=8500, rhobar0=1.2)
+    grid = d["grid"]
+    lprop.grid, lprop.grids = grid, .5 * (grid[:-1] + grid[1:])
+    lprop.set_hydrostatics()
+    np.testing.assert_array_equal(lprop.rhobar, d["rhobar"])
+    lprop.pressure_gradient = d["pg"].copy()
+    lprop.set_statics(dkk=d["dkk"], dll=d["dll"], rr_mm_area=d["area"])
+
+
+def _obj(st):
+    o = np.empty(11, dtype=object)
+    for i, a in enumerate(st):
+        o[i] = a
+    return o
+
+
+def _check(got, d, prefix, tol=1e-10):
+    scale = max(np.max(np.abs(d[f"{prefix}_uu"])), np.max(np.abs(d[f"{prefix}_vv"])), 1e-300)
+    for i, k in enumerate(STATE_KEYS):
+        want = d[f"{prefix}_{k}"]
+        assert isinstance(got[i], np.ndarray) and got[i].dtype == np.float64 and got[i].shape == want.shape
+        if k in ("uu", "vv"):
+            assert np.max(np.abs(got[i] - want)) / scale <= tol, k
+        else:
+            assert relerr(got[i], want) <= tol, (k, relerr(got[i], want))
+
+
+def test_rk3_and_rhs_default_match_reference():
+    import msgwam_amd.libprop as lprop
+    d = load("g3_rk3_coupled_f45")
+    _configure_from(d, lprop)
+    st = _obj(state_from(d, "in"))
+    out = lprop.RK3(float(d["dt"]), st)
+    assert out.dtype == object and out.shape == (11,)
+    _check(out, d, "s1")
+    for _ in range(9):                     # feed the returned object back: state stays resident
+        out = lprop.RK3(float(d["dt"]), out)
+    _check(out, d, "s10")
+    g = load("g1_rhs_f45_sat1")
+    _configure_from(g, lprop)
+    t = lprop.rhs_default(float(g["dt"]), _obj(state_from(g, "in")))
+    _check(t, g, "out", tol=1e-12)
+    lprop.release_device()
+
+
+def test_fixed_background_hook_config1():
+    """BASELINE config 1 through the module surface: rhs hook that freezes the column."""
+    import msgwam_amd.libprop as lprop
+    d = load("g3_rk3_fixedbg_config1")
+    _configure_from(d, lprop)
+    lprop.set_model_setup(rhs=lprop.rhs_fixed_background)
+    out = _obj(state_from(d, "in"))
+    for n in range(1, 101):
+        out = lprop.RK3(float(d["dt"]), out)
+        if n in (1, 10, 100):
+            _check(out, d, f"s{n}")
+    lprop.set_model_setup(rhs=lprop.rhs_default)
+    lprop.release_device()
+
+
+def test_nray_equal_to_levels_works():
+    """nray == ngrid-1 crashes the reference (object-array collapse); the mirror must not."""
+    import msgwam_amd.libprop as lprop
+    from msgwam_amd import driver
+    grid, grids, uu, vv = driver.configure(ngrid=101)
+    ic = driver.initial_rays(100, grids)
+    st = _obj([ic[k] for k in driver.KEYS] + [uu, vv])
+    out = lprop.RK3(120.0, st)
+    assert out.shape == (11,) and out[3].shape == (100,) and out[9].shape == (100,)
+    assert np.all(np.isfinite(out[3]))
+    lprop.release_device()
+
+
+def test_scope_errors_are_loud():
+    import msgwam_amd.libprop as lprop
+    d = load("g3_rk3_coupled_driver")
+    _configure_from(d, lprop)
+    st = _obj(state_from(d, "in"))
+    lprop.HPROP_GLOBAL = True
+    with pytest.raises(NotImplementedError):
+        lprop.RK3(120.0, st)
+    lprop.HPROP_GLOBAL = False
+    lprop.set_model_setup(rhs=lambda dt, v: v)
+    with pytest.raises(TypeError):
+        lprop.RK3(120.0, st)
+    lprop.set_model_setup(rhs=lprop.rhs_default)
+    with pytest.raises(NotImplementedError):
+        lprop.wave_projection(*([np.ones(4)] * 12), d["grid"], var=3)
+    lprop.release_device()
+
+
+@pytest.mark.parametrize("mode,nt,every", [("dropin", 100, 1), ("resident", 1000, 10)])
+def test_driver_matches_reference_loop(mode, nt, every):
+    """raytracer.py's own loop (60 rays, direct saturation with the `/1` quirk)."""
+    from msgwam_amd import driver
+    d = load("g4_saturation_direct_driver")
+    H = driver.run(nray=60, nt_max=nt, mode=mode, snapshot_every=every, diagnostics=(mode == "dropin"))
+    for n in (10, 100, 710, 1000):
+        if n > nt or n % every:
+            continue
+        for k in ("dens", "rr", "mm"):
+            assert relerr(H[f"int_{k}"][n], d[f"s{n}_{k}"]) <= 1e-10, (n, k)
+        scale = np.max(np.abs(d[f"s{n}_uu"]))
+        assert np.max(np.abs(H["int_uu"][n] - d[f"s{n}_uu"])) / scale <= 1e-10
+    if mode == "dropin":
+        assert relerr(H["int_dens_prop"][100], d["s100_dens_prop"]) <= 1e-10
+        # conservation diagnostic (raytracer.py:198-240): wave action is projected and finite
+        assert H["wa"].shape == (nt + 1, 100) and np.all(np.isfinite(H["wa"])) and H["wa"].max() > 0

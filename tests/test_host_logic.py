@@ -1,0 +1,59 @@
+"""CPU-only: host-side logic of the product package (no GPU compute): module surface,
+column/initial-condition helpers, spectrum generator and sharding."""
+import numpy as np
+
+from oracle import msgwam_oracle as orc
+from helpers import load
+
+
+def test_module_surface_mirrors_the_reference():
+    import msgwam_amd.libprop as lprop
+    for name in ("HPROP_GLOBAL", "grid", "grids", "rhobar", "pressure_gradient", "model_config", "statics",
+                 "ROT_EARTH", "RAD_EARTH", "set_statics", "set_model_setup", "get_model_setup",
+                 "set_hydrostatics", "set_pressure_gradient", "velocities_sine_homogeneous", "omega",
+                 "rhs_default", "RK3", "saturation", "wave_projection"):
+        assert hasattr(lprop, name), name
+    # defaults as at import of lib/libprop.py:703-726
+    assert lprop.model_config["rhs"] is lprop.rhs_default
+    assert lprop.model_config["kappa"] == 0.95 and lprop.model_config["saturate_online"] is True
+    assert lprop.statics["rr_mm_area"] == 0
+
+
+def test_column_helpers_match_the_reference_values():
+    import msgwam_amd.libprop as lprop
+    d = load("g3_rk3_coupled_f45")
+    lprop.set_model_setup(bvf=0.01, boussinesq=False, sig_rr=10000, u0=4, rr0=40000, phi0=float(d["phi0"]),
+                          hh=8500, rhobar0=1.2)
+    grid = d["grid"]
+    lprop.grid, lprop.grids = grid, .5 * (grid[:-1] + grid[1:])
+    lprop.set_hydrostatics()
+    np.testing.assert_array_equal(lprop.rhobar, d["rhobar"])
+    uu = lprop.velocities_sine_homogeneous(lprop.grids)
+    np.testing.assert_array_equal(uu, d["in_uu"])
+    lprop.set_pressure_gradient(uu, d["in_vv"])
+    np.testing.assert_array_equal(lprop.pressure_gradient, d["pg"])
+    kk, ll, mm = d["in_kk"], d["in_ll"], d["in_mm"]
+    np.testing.assert_array_equal(lprop.omega(kk, ll, mm, float(d["phi0"])),
+                                  orc.omega(kk, ll, mm, float(d["phi0"]), 0.01))
+
+
+def test_spectrum_is_deterministic_and_shardable():
+    from msgwam_amd.spectrum import gaussian_spectrum
+    from msgwam_amd.sharding import shard_bounds, shard_state
+    s0 = orc.Setup(np.linspace(0, 100e3, 101))
+    full = gaussian_spectrum(8000, s0.grids, s0.rhobar, nz=20)
+    parts = []
+    for r in range(4):
+        lo, hi = shard_bounds(8000, 4, r)
+        assert lo % 2 == 0
+        parts.append(gaussian_spectrum(8000, s0.grids, s0.rhobar, nz=20, start=lo, stop=hi))
+    for k in full:
+        np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), full[k])
+    # z-major, then azimuth, then m: consecutive rays share height and direction
+    assert np.all(np.diff(full["rr"]) >= 0)
+    assert np.all(full["kk"][:100] == full["kk"][0]) and np.all(np.diff(full["mm"][:100]) > 0)
+    assert np.all(full["dens"] > 0) and np.all(np.isfinite(full["dens"]))
+    st = [full[k] for k in ("dens", "lam", "phi", "rr", "drr", "kk", "ll", "mm", "dmm")] + [np.zeros(100)] * 2
+    cover = [shard_state(st, 3, r)[3] for r in range(3)]
+    np.testing.assert_array_equal(np.concatenate(cover), full["rr"])
+    assert [shard_bounds(7, 3, r) for r in range(3)] == [(0, 2), (2, 4), (4, 7)]
