@@ -122,6 +122,7 @@ struct msgw_ctx {
     // rccl
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    bool force_coll = false;
 
     // counters / kernel timing
     msgw_counters_t cnt{};
@@ -446,7 +447,7 @@ int column_stage(msgw_ctx *c, const ColArgs &a0)
 {
     ColArgs a = a0;
     if (int rc = reduce_level1(c, a)) return rc;
-    if (c->nranks > 1) {
+    if (c->nranks > 1 || (c->force_coll && c->comm)) {
         if (int rc = launch_column_t<STAGE, COL_REDUCE>(c, a)) return rc;
         if (int rc = allreduce_flux(c)) return rc;
         return launch_column_t<STAGE, COL_UPDATE>(c, a);
@@ -513,7 +514,7 @@ int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_k
             if (pending) cur ^= 1;     // workgroup 0 has published the updated column there
             rows = make_col_args(c, dt, flags);
             rows.partial = c->grp_rows; rows.ranges = nullptr; rows.nblocks = c->ngroups;   // dense group rows
-            if (c->nranks > 1) {       // local rows -> one flux row, summed over the ranks
+            if (c->nranks > 1 || (c->force_coll && c->comm)) {   // local rows -> one flux row, summed over the ranks
                 if ((rc = launch_column_t<4, COL_REDUCE>(c, rows))) return rc;
                 if ((rc = allreduce_flux(c))) return rc;
                 rows.partial = c->flux; rows.ranges = nullptr; rows.nblocks = 1;
@@ -990,6 +991,9 @@ int msgw_comm_init(msgw_ctx *c, const void *id128, int rank, int nranks)
     c->rank = rank;
     c->nranks = nranks;
     c->cnt.nranks = nranks;
+    // MSGW_FORCE_COLLECTIVE=1: run the all-reduce chain even for a 1-rank communicator, so that the
+    // multi-GPU code path (reduce -> ncclAllReduce -> 1-row prologue) can be tested on a 1-GPU box
+    if (const char *e = std::getenv("MSGW_FORCE_COLLECTIVE")) c->force_coll = std::atoi(e) != 0;
     drop_graph(c);
     return MSGW_OK;
 }

@@ -262,3 +262,48 @@ def test_full_size_config3_properties_and_subsample():
     check_state(got, want, 1e-10, 1e-11, "config3")
     assert not np.array_equal(got[9], st[9])                   # the mean flow really moved
     p.close()
+
+
+def test_tall_column_path_vs_c_oracle():
+    """ngrid = 301 (> 130 levels): per-level sums stay in LDS, standalone column kernel per stage."""
+    rng = np.random.default_rng(77)
+    n = 30_011
+    grid = np.linspace(0, 150e3, 301)
+    area = rng.uniform(1e-3, 1e-1, n)
+    s = orc.Setup(grid, phi0=0.2, kappa=0.9, saturate_online=False, dkk=np.full(n, 1e-4), dll=np.full(n, 1e-4),
+                  rr_mm_area=area)
+    uu = orc.velocities_sine_homogeneous(s.grids, 4.0, 40e3, 10e3)
+    vv = 0.1 * uu[::-1].copy()
+    s.set_pressure_gradient(uu, vv)
+    rr = np.sort(rng.uniform(-1e3, 155e3, n))
+    drr = rng.uniform(50, 1500, n)
+    # weak forcing (dens <= 1e7): with dens ~ 1e9 this setup drives uu by 10 m/s per step and
+    # amplifies summation-order noise x500 per step (3.7e-14 -> 9e-10 in three steps)
+    st = [rng.uniform(0, 1e7, n), np.zeros(n), np.full(n, 0.2), rr, drr, rng.normal(0, 1e-4, n),
+          rng.normal(0, 1e-4, n), rng.normal(0, 2e-3, n), area / drr, uu, vv]
+    want = COracle(s).step(60.0, 3, st)
+    p = make_prop(s, st)
+    p.step(60.0, 3)
+    check_state(gpu_state(p, st), want, 1e-10, 1e-11, "tall")
+    p.close()
+
+
+def test_collective_chain_with_one_rank_communicator(monkeypatch):
+    """The multi-GPU chain (k_column<reduce> -> ncclAllReduce -> 1-row prologue) exercised with a
+    1-rank RCCL communicator: results must equal the plain single-GPU path bit for bit
+    (an all-reduce over one rank is the identity)."""
+    monkeypatch.setenv("MSGW_FORCE_COLLECTIVE", "1")
+    s, st = _random_case(120_000, 41, False, "uniform", True)
+    ref = make_prop(s, st)
+    ref.step(60.0, 5)
+    want = gpu_state(ref, st)
+    ref.close()
+    for graph_steps in (0, 2):
+        p = make_prop(s, st)
+        p.comm_init(_capi.comm_unique_id(), 0, 1)
+        p.set_tuning(4, graph_steps)
+        p.step(60.0, 5)
+        got = gpu_state(p, st)
+        assert p.counters()["nranks"] == 1
+        p.close()
+        check_state(got, want, 1e-12, 1e-12, f"collective graph={graph_steps}")
