@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "column_kernels.h"
+#include "persist_kernel.h"
 #include "ray_kernels.h"
 
 using namespace msgw;
@@ -95,7 +96,6 @@ struct msgw_ctx {
 
     // launch geometry + per-workgroup flux rows
     int blocks_per_cu = 4;
-    int prefetch = 0;                // register double-buffering in the ray-stage kernel
     int blocks = 0, tiles_per_block = 0;
     double *partial = nullptr;
     size_t partial_elems = 0;
@@ -109,6 +109,11 @@ struct msgw_ctx {
     size_t grp_part_elems = 0;
     int grp_size = 1, ngroups = 1, row_stride = 0;
     bool groupred = false;           // set while enqueueing fused stages
+    // persistent RK3 kernel (single rank, coupled)
+    int persist = 1;                 // 0 disables (MSGW_PERSIST=0 or after a time-out)
+    double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
+    unsigned int *pdone = nullptr;   // [0] done counter, [1] status (as int), [2] ready counter
+    double *flux2 = nullptr;         // [2][ncols] final flux rows of the persistent kernel
 
     // graph
     int graph_steps = 0;
@@ -265,6 +270,9 @@ int ensure_groups(msgw_ctx *c)
     if (!c->grp_rows) {
         HIPCHK(c, hipMalloc(&c->grp_rows, sizeof(double) * (size_t)FUSE_ROWS * 2 * (c->ng - 2)));
         HIPCHK(c, hipMalloc(&c->grp_cnt, sizeof(unsigned int) * 64));
+        HIPCHK(c, hipMalloc(&c->grp_rows2, sizeof(double) * (size_t)2 * PERSIST_GROUPS * 2 * (c->ng - 2)));
+        HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * 4));
+        HIPCHK(c, hipMalloc(&c->flux2, sizeof(double) * (size_t)2 * 2 * (c->ng - 2)));
     }
     HIPCHK(c, hipMemsetAsync(c->grp_cnt, 0, sizeof(unsigned int) * 64, c->stream));
     return MSGW_OK;
@@ -373,12 +381,10 @@ template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
 int launch_stage_t(msgw_ctx *c, const StageArgs &a)
 {
     if (c->ng - 2 > 128)   // tall columns: per-level sums stay in LDS (NH = 0)
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false, 0>, stage_lds_bytes(c->ng), a);
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 0>, stage_lds_bytes(c->ng), a);
     if (c->groupred && DEPOSIT && STAGE != 3)   // fused chain: first-level flux reduction inside the kernel
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false, 2, (DEPOSIT && STAGE != 3)>, stage_lds_bytes(c->ng), a);
-    if (c->prefetch && c->tiles_per_block > 1 && STAGE != 3)
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, (STAGE != 3), 2>, stage_lds_bytes(c->ng), a);
-    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, false, 2>, stage_lds_bytes(c->ng), a);
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, (DEPOSIT && STAGE != 3)>, stage_lds_bytes(c->ng), a);
+    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2>, stage_lds_bytes(c->ng), a);
 }
 
 // mode: 0 plain, 1 online saturation, 2 direct (driver) saturation
@@ -453,6 +459,83 @@ int column_stage(msgw_ctx *c, const ColArgs &a0)
         return launch_column_t<STAGE, COL_UPDATE>(c, a);
     }
     return launch_column_t<STAGE, COL_REDUCE | COL_UPDATE>(c, a);
+}
+
+size_t persist_lds_bytes(int ng)
+{
+    return stage_lds_bytes(ng) + sizeof(double) * (size_t)7 * (ng - 1) + 32;
+}
+
+template <bool SAT, bool FVEC, bool DIRECT>
+int launch_persist_t(msgw_ctx *c, const PersistArgs &pa, bool *resident)
+{
+    auto k = k_rk3_persist<SAT, FVEC, DIRECT>;
+    const size_t lds = persist_lds_bytes(c->ng);
+    if (int rc = ensure_lds(c, k, lds)) return rc;
+    int per_cu = 0;
+    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, BLOCK, lds));
+    *resident = (long long)per_cu * c->ncu >= c->blocks;       // every workgroup must be co-resident
+    if (!*resident) return MSGW_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->time_next) {
+        hipEvent_t *ev = timing_events(c);
+        if (ev) { e0 = ev[0]; e1 = ev[1]; }
+    }
+    hipExtLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, e0, e1, 0, pa);
+    HIPCHK(c, hipGetLastError());
+    return MSGW_OK;
+}
+
+// All `count` steps in ONE persistent launch.  *used = false when the path does not apply
+// (then nothing was enqueued and the caller takes the per-stage path).
+int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_kernels, bool *used)
+{
+    *used = false;
+    const bool can_fuse = (2 * (c->ng - 2) <= BLOCK) && (c->ng - 1 <= BLOCK);
+    if (!c->persist || !can_fuse || c->nranks > 1 || (c->force_coll && c->comm) || (flags & MSGW_FIXED_BACKGROUND) || count <= 0)
+        return MSGW_OK;
+    const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
+    PersistArgs pa{};
+    pa.s = make_stage_args(c, dt, flags);
+    pa.s.grp_size = (c->blocks + PERSIST_GROUPS - 1) / PERSIST_GROUPS;
+    pa.ngroups = (c->blocks + pa.s.grp_size - 1) / pa.s.grp_size;
+    pa.nsteps = count;
+    pa.grp_rows2 = c->grp_rows2;
+    pa.done = c->pdone;
+    pa.status = reinterpret_cast<int *>(c->pdone + 1);
+    pa.ready = c->pdone + 2;
+    pa.flux2 = c->flux2;
+    pa.timeout_ticks = 20000000ull;                            // 0.2 s of wall clock per wait
+    pa.cin = ColIn{c->uu, c->vv, c->q_uu, c->q_vv};
+    pa.cout = ColOut{c->uu, c->vv, c->q_uu, c->q_vv};
+    pa.dudz = c->dudz; pa.dvdz = c->dvdz; pa.slu = c->slu; pa.slv = c->slv;
+    HIPCHK(c, hipMemsetAsync(c->pdone, 0, sizeof(unsigned int) * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->grp_cnt, 0, sizeof(unsigned int) * 64, c->stream));
+    bool resident = false;
+    c->time_next = time_kernels;
+    int rc = MSGW_OK;
+    const bool fv = c->fvec;
+    if (mode == 1) rc = fv ? launch_persist_t<true, true, false>(c, pa, &resident) : launch_persist_t<true, false, false>(c, pa, &resident);
+    else if (mode == 2) rc = fv ? launch_persist_t<false, true, true>(c, pa, &resident) : launch_persist_t<false, false, true>(c, pa, &resident);
+    else rc = fv ? launch_persist_t<false, true, false>(c, pa, &resident) : launch_persist_t<false, false, false>(c, pa, &resident);
+    c->time_next = false;
+    if (rc) return rc;
+    if (!resident) return MSGW_OK;                             // grid larger than residency: per-stage path
+    *used = true;
+    c->cnt.persist_steps = count;
+    // the waits are bounded; a raised status means a workgroup was not resident (or the GPU is
+    // shared): report it loudly, never spin forever
+    int status = 0;
+    HIPCHK(c, hipMemcpyAsync(&status, c->pdone + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (status != 0) {
+        c->persist = 0;
+        c->have_rays = false;                                  // the step was abandoned half-way
+        return fail(c, MSGW_ERR_HIP, "persistent RK3 kernel timed out waiting for other workgroups "
+                    "(not all %d workgroups resident?); state is invalid, upload the rays again "
+                    "(the per-stage kernels will be used from now on)", c->blocks);
+    }
+    return MSGW_OK;
 }
 
 // Enqueue `count` RK3 steps (lib/libprop.py:693-698) on the context's stream.
@@ -553,6 +636,8 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     if (!out) return fail(nullptr, MSGW_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (nray_cap < 1 || ngrid < 4) return fail(nullptr, MSGW_ERR_ARG, "need nray_cap >= 1 and ngrid >= 4");
+    if (nray_cap > (1ll << 29))
+        return fail(nullptr, MSGW_ERR_ARG, "at most 2^29 rays per context (32-bit byte offsets into the SoA arrays)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, MSGW_ERR_NOGPU, "no HIP device visible (this library has no CPU fallback)");
@@ -595,6 +680,7 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
 #undef CR
     c->cnt.ngrid = ngrid;
     c->cnt.nranks = 1;
+    if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     *out = c;
     return MSGW_OK;
 }
@@ -615,6 +701,9 @@ int msgw_destroy(msgw_ctx *c)
     if (c->grp_part) (void)hipFree(c->grp_part);
     if (c->grp_rows) (void)hipFree(c->grp_rows);
     if (c->grp_cnt) (void)hipFree(c->grp_cnt);
+    if (c->grp_rows2) (void)hipFree(c->grp_rows2);
+    if (c->pdone) (void)hipFree(c->pdone);
+    if (c->flux2) (void)hipFree(c->flux2);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -714,7 +803,6 @@ int msgw_set_tuning(msgw_ctx *c, int blocks_per_cu, int graph_steps)
     if (!c) return MSGW_ERR_ARG;
     if (blocks_per_cu < 1 || blocks_per_cu > 64 || graph_steps < 0 || graph_steps > 64)
         return fail(c, MSGW_ERR_ARG, "blocks_per_cu in [1,64], graph_steps in [0,64]");
-    if (const char *e = std::getenv("MSGW_PREFETCH")) c->prefetch = std::atoi(e) ? 1 : 0;
     c->blocks_per_cu = blocks_per_cu;
     c->graph_steps = graph_steps;
     drop_graph(c);
@@ -740,7 +828,13 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
     if (time_kernels) c->kev_used = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     int done = 0;
-    if (!eager && nsteps >= c->graph_steps) {
+    {
+        bool used = false;
+        c->cnt.persist_steps = 0;
+        if (int rc = run_persistent(c, dt, gflags, nsteps, time_kernels, &used)) return rc;
+        if (used) done = nsteps;
+    }
+    if (done < nsteps && !eager && nsteps >= c->graph_steps) {
         if (!c->gexec || c->g_dt != dt || c->g_flags != gflags || c->g_n != c->n || c->g_steps != c->graph_steps) {
             drop_graph(c);
             bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -764,7 +858,8 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
             done += c->g_steps;
         }
     }
-    if (int rc = enqueue_steps(c, dt, gflags, nsteps - done, time_kernels)) return rc;
+    if (done < nsteps)
+        if (int rc = enqueue_steps(c, dt, gflags, nsteps - done, time_kernels)) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
     c->cnt.graph_steps = c->gexec ? c->g_steps : 0;

@@ -1,0 +1,278 @@
+// Persistent RK3 kernel (single-GPU coupled path): all workgroups stay resident for `nsteps`
+// RK3 steps = 3*nsteps stages.  Per stage a workgroup
+//   (1) issues its first tile's ray loads (they do not depend on the other workgroups),
+//   (2) waits -- bounded spin of ONE lane on ONE counter -- until the previous stage's final flux
+//       row has been published, and advances its own LDS replica of the column
+//       (uu, vv, q_uu, q_vv never touch global memory inside the launch),
+//   (3) runs its tiles (process_tiles), publishes its flux row, takes a ticket; the last arriver of
+//       each group adds the group's rows; the reducer that completes the stage's last group adds
+//       the group sums into the final flux row and bumps the stage counter.
+// So one stage's reduction tail overlaps the next stage's load wait, and there is no kernel
+// boundary, no column kernel and no global column traffic between stages.
+//
+// Cross-workgroup data (flux rows, group sums) is re-published at the same addresses every
+// stage inside ONE launch, so every load and store of it is an 8-byte agent-scope atomic
+// (sc1): coherent by the memory model, no reliance on L1/L2 state.  Order: stores -> every
+// storing wave s_waitcnt vmcnt(0) -> barrier -> relaxed agent fetch_add; consumer: relaxed poll
+// -> barrier -> sc1 loads only (cdna_hip_programming.md Guideline 16, the all-sc1 form: no
+// L1-invalidating acquire, which costs microseconds per workgroup at 4 workgroups per CU).
+//
+// Every wait is bounded (wall clock); on time-out a status word is raised and all workgroups
+// leave.  The host sizes the grid from the occupancy query (all workgroups must be resident).
+#pragma once
+#include "ray_kernels.h"
+
+namespace msgw {
+
+constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
+
+struct PersistArgs {
+    StageArgs s;                  // rays, constants, static column tables; grp_part/grp_cnt/grp_size/row_stride
+    int nsteps;
+    int ngroups;
+    double *grp_rows2;            // [2][PERSIST_GROUPS][2*(ng-2)] parity-buffered group sums
+    double *flux2;                // [2][2*(ng-2)] parity-buffered final flux row of a stage
+    unsigned int *done;           // completed group reductions since launch (zeroed before launch)
+    unsigned int *ready;          // stages whose final flux row is published (zeroed before launch)
+    int *status;                  // 0 ok, 1 a wait timed out
+    unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
+    ColIn cin;                    // canonical column at entry
+    ColOut cout;                  // canonical column at exit (workgroup 0)
+    double *dudz, *dvdz, *slu, *slv;    // derived tables at exit (workgroup 0)
+};
+
+typedef unsigned long long u64_t;
+
+__device__ __forceinline__ double ld_agent(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64_t *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<u64_t *>(p), (u64_t)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Wait until *ready >= target stages (one lane polls, bounded), then release the workgroup.
+__device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int target, int *s_flag, int tid)
+{
+    if (tid == 0) {
+        int ok = 1;
+        if (__hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(8);
+                if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                    wall_clock64() - t0 > p.timeout_ticks) {
+                    __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        // No agent-scope acquire (buffer_inv sc1 costs microseconds per workgroup at 4 workgroups/CU):
+        // every handed-off byte is read with an sc1 (agent-scope atomic) load that bypasses L1, so
+        // only the compiler must be kept from hoisting those loads above the poll.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        *s_flag = ok;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+// Publish this workgroup's row, ticket, group reduction by the last arriver (all cross-workgroup
+// accesses are agent-scope atomics), completion counted on p.done.
+__device__ __forceinline__ void persist_publish(const PersistArgs p, const double *rows, int ncp, int *s_flag,
+                                                int tid, unsigned int q)
+{
+    const StageArgs a = p.s;
+    const int ncols = 2 * ncp;
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int g = b / a.grp_size, r0 = g * a.grp_size, r1 = min(nb, r0 + a.grp_size);
+    __syncthreads();                                          // all waves' rows complete in LDS
+    double *mine = a.grp_part + (size_t)b * a.row_stride;
+    for (int col = tid; col < ncols; col += BLOCK) {
+        double acc = rows[col];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) acc = acc + rows[w * ncols + col];
+        st_agent(mine + col, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(a.grp_cnt + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: rows are read with sc1 loads
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+    double *dst = p.grp_rows2 + ((size_t)(q & 1) * PERSIST_GROUPS + g) * ncols;
+    if (tid < ncols) {
+        const double *src = a.grp_part + tid;
+        double acc = 0.0;
+        for (int r = r0; r < r1; r += 32) {                   // row order, 32 loads in flight
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = ld_agent(src + (size_t)min(r + u, r1 - 1) * a.row_stride);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc = acc + ((r + u < r1) ? v[u] : 0.0);
+        }
+        st_agent(dst + tid, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(a.grp_cnt + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm the ticket
+        const unsigned int t2 = __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        *s_flag = (t2 == (q + 1u) * (unsigned int)p.ngroups - 1u) ? 1 : 0;   // last group of this stage?
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+    // third level: the reducer of the stage's last group adds the group sums (group order) into
+    // ONE final flux row, so that every workgroup reads 2*(ng-2) values instead of ngroups times that
+    if (tid < ncols) {
+        const double *src = p.grp_rows2 + (size_t)(q & 1) * PERSIST_GROUPS * ncols + tid;
+        double tot = 0.0;
+        for (int r = 0; r < p.ngroups; r += 32) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = ld_agent(src + (size_t)min(r + u, p.ngroups - 1) * ncols);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) tot = tot + ((r + u < p.ngroups) ? v[u] : 0.0);
+        }
+        st_agent(p.flux2 + (size_t)(q & 1) * ncols + tid, tot);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct PersistLds {
+    double4 *sh; double2 *rho2; double *xg, *gs, *rows;
+    double *cu, *cv, *cqu, *cqv, *crho, *cpg;     // column replica + static rhobar, pg [2][nc]
+    double *F, *u, *v, *du, *dv;                  // scratch (aliases rows)
+    int *flag;
+};
+
+// apply the mean-flow update of stage `pstage` from the group sums of global stage q-1
+__device__ __forceinline__ void persist_column(const PersistArgs p, const PersistLds L, unsigned int q,
+                                               int pstage, int tid)
+{
+    const StageArgs a = p.s;
+    const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2, ncols = 2 * ncp;
+    if (tid < ncols) {
+        const int pp = tid / ncp, c = tid - pp * ncp;
+        L.F[pp * ng + 1 + c] = ld_agent(p.flux2 + (size_t)((q - 1) & 1) * ncols + tid);   // pm_flux[:, 1:-1] (:654)
+    }
+    __syncthreads();
+    column_flux_ends(tid, ng, L.F);
+    __syncthreads();
+    if (tid < nc) {
+        double du, dv, un, vn, qu, qv;
+        column_tendency(tid, ng, a.f0, a.dzg, 0, L.F, L.crho[tid], L.cpg[tid], L.cpg[nc + tid], L.cu[tid],
+                        L.cv[tid], du, dv);
+        column_rk(pstage, a.dt, du, dv, L.cu[tid], L.cv[tid], L.cqu[tid], L.cqv[tid], un, vn, qu, qv);
+        L.cu[tid] = un; L.cv[tid] = vn; L.cqu[tid] = qu; L.cqv[tid] = qv;
+    }
+    __syncthreads();
+    column_shear(tid, BLOCK, ng, a.dzg, L.cu, L.cv, L.du, L.dv);
+    __syncthreads();
+    for (int i = tid; i < ni; i += BLOCK) {
+        const bool in = i < ni - 1;
+        L.sh[i] = make_double4(L.du[i], in ? column_slope(L.du, L.xg, i) : 0.0,
+                               L.dv[i], in ? column_slope(L.dv, L.xg, i) : 0.0);
+    }
+    __syncthreads();
+}
+
+template <int STAGE, bool SAT, bool FVEC, bool DIRECT>
+__device__ __forceinline__ bool persist_stage(const PersistArgs p, const PersistLds L, unsigned int q,
+                                              long long tile0, int tid, int wave, int lane)
+{
+    const StageArgs a = p.s;
+    const int ncp = a.ng - 2;
+    // Opaque copies: without them the three inlined stage bodies share (CSE) every per-array tile
+    // address and keep ~60 VGPRs of 64-bit addresses alive across the whole step.
+    asm volatile("" : "+s"(tile0));
+    asm volatile("" : "+v"(tid));
+    TileRegs cur;
+    // wave 0 polls and fences (its acquire waits for its own outstanding loads), so it loads after
+    if (wave != 0 || q == 0) load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, tile0 * (long long)TILE, tid);
+    if (q > 0) {
+        if (!persist_wait(p, q, L.flag, tid)) return false;
+        if (wave == 0) load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, tile0 * (long long)TILE, tid);
+        persist_column(p, L, q, (STAGE + 2) % 3, tid);
+    }
+    for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
+    __syncthreads();
+    int wmin = INT_MAX, wmax = INT_MIN;
+    const StageLds SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
+    process_tiles<STAGE, SAT, FVEC, true, DIRECT, 2>(a, SL, cur, tile0, tid, wave, lane, wmin, wmax);
+    persist_publish(p, L.rows, ncp, L.flag, tid, q);
+    return true;
+}
+
+template <bool SAT, bool FVEC, bool DIRECT>
+__global__ void __launch_bounds__(BLOCK) k_rk3_persist(const PersistArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const StageArgs a = p.s;
+    const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
+    PersistLds L;
+    L.sh = reinterpret_cast<double4 *>(lds);
+    L.rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);
+    L.xg = lds + 4 * ni + 2 * nc;
+    L.gs = L.xg + ni;
+    L.rows = L.gs + nc;
+    double *colrep = L.rows + WAVES * 2 * ncp;
+    L.cu = colrep; L.cv = L.cu + nc; L.cqu = L.cv + nc; L.cqv = L.cqu + nc; L.crho = L.cqv + nc; L.cpg = L.crho + nc;
+    L.flag = reinterpret_cast<int *>(L.cpg + 2 * nc);
+    L.F = L.rows; L.u = L.F + 2 * ng; L.v = L.u + nc; L.du = L.v + nc; L.dv = L.du + ni;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
+
+    for (int i = tid; i < ni; i += BLOCK) L.xg[i] = a.c.xg[i];
+    for (int i = tid; i < nc; i += BLOCK) {
+        L.gs[i] = a.c.grids[i];
+        L.rho2[i] = make_double2(a.c.rhobar[i], (i < nc - 1) ? a.c.slrho[i] : 0.0);
+        L.cu[i] = p.cin.uu[i]; L.cv[i] = p.cin.vv[i]; L.cqu[i] = 0.0; L.cqv[i] = 0.0;
+        L.crho[i] = a.c.rhobar[i]; L.cpg[i] = a.pg[i]; L.cpg[nc + i] = a.pg[nc + i];
+    }
+    __syncthreads();
+    column_shear(tid, BLOCK, ng, a.dzg, L.cu, L.cv, L.du, L.dv);
+    __syncthreads();
+    for (int i = tid; i < ni; i += BLOCK) {
+        const bool in = i < ni - 1;
+        L.sh[i] = make_double4(L.du[i], in ? column_slope(L.du, L.xg, i) : 0.0,
+                               L.dv[i], in ? column_slope(L.dv, L.xg, i) : 0.0);
+    }
+    __syncthreads();
+
+    unsigned int q = 0;
+    for (int step = 0; step < p.nsteps; ++step) {
+        if (!persist_stage<0, SAT, FVEC, DIRECT>(p, L, q, tile0, tid, wave, lane)) return;
+        ++q;
+        if (!persist_stage<1, SAT, FVEC, DIRECT>(p, L, q, tile0, tid, wave, lane)) return;
+        ++q;
+        if (!persist_stage<2, SAT, FVEC, DIRECT>(p, L, q, tile0, tid, wave, lane)) return;
+        ++q;
+    }
+    if (blockIdx.x != 0) return;
+    // workgroup 0 applies the last pending update and writes the column back
+    if (!persist_wait(p, q, L.flag, tid)) return;
+    persist_column(p, L, q, 2, tid);
+    for (int i = tid; i < nc; i += BLOCK) {
+        p.cout.uu[i] = L.cu[i]; p.cout.vv[i] = L.cv[i]; p.cout.q_uu[i] = L.cqu[i]; p.cout.q_vv[i] = L.cqv[i];
+    }
+    for (int i = tid; i < ni; i += BLOCK) {
+        const double4 t = L.sh[i];
+        p.dudz[i] = t.x; p.dvdz[i] = t.z;
+        if (i < ni - 1) { p.slu[i] = t.y; p.slv[i] = t.w; }
+    }
+}
+
+}   // namespace msgw

@@ -139,14 +139,17 @@ __device__ __forceinline__ int wave_max(int v)
 // with inert rays), so all accesses are UNCONDITIONAL 16-B vector accesses: a conditional
 // load makes hipcc branch around it and wait vmcnt(0) per load, which serialises the nine
 // streams of a tile into nine memory round trips (measured: 27 us vs 16 us per launch).
-__device__ __forceinline__ void load2(const double *p, long long i0, double (&out)[2])
+// Addressing: uniform base pointer (SGPR pair) + ONE 32-bit byte offset shared by all SoA
+// arrays of a tile (global_load ... v_off, s[base] form) instead of a 64-bit VGPR address
+// per array: saves ~26 VGPRs and the address arithmetic.  Limits a context to 2^29 rays.
+__device__ __forceinline__ void load2(const double *p, unsigned int off, double (&out)[2])
 {
-    const double2 t = *reinterpret_cast<const double2 *>(p + i0);       // 16 B per lane
+    const double2 t = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(p) + off);   // 16 B per lane
     out[0] = t.x; out[1] = t.y;
 }
-__device__ __forceinline__ void store2(double *p, long long i0, const double (&v)[2])
+__device__ __forceinline__ void store2(double *p, unsigned int off, const double (&v)[2])
 {
-    *reinterpret_cast<double2 *>(p + i0) = make_double2(v[0], v[1]);
+    *reinterpret_cast<double2 *>(reinterpret_cast<char *>(p) + off) = make_double2(v[0], v[1]);
 }
 
 // ------------------------------------------------------------------ np.interp on an LDS column
@@ -354,7 +357,7 @@ __device__ __forceinline__ void flush_rows(const double *rows, int ncp, int *s_r
 // recipe (sc1 payload + drained vmcnt + barrier + relaxed agent fetch_add; consumer acquire).
 template <int NP>
 __device__ __forceinline__ void flush_rows_group(const double *rows, int ncp, int *s_flag, double *s_scr,
-                                                 int tid, const StageArgs &a)
+                                                 int tid, const StageArgs a)
 {
     typedef unsigned long long u64;
     const int ncols = NP * ncp;
@@ -445,131 +448,66 @@ __device__ __forceinline__ double sat_cap(double sat_c, double rho_f, double omh
 struct TileRegs {
     double rr[2], mm[2], kk[2], ll[2], dens[2], drr[2], vol[2], ff[2], pvf[2];
     double qr[2], qm[2], qd[2], rr0[2], mm0[2];
-    long long i0;
+    unsigned int off;     // byte offset of this lane's ray pair in every SoA array
     bool v0, v1;
 };
 
 template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
-__device__ __forceinline__ void load_tile(TileRegs &t, const StageArgs &a, long long base, int tid)
+__device__ __forceinline__ void load_tile(TileRegs &t, const StageArgs a, long long base, int tid)
 {
     constexpr bool NEED_RHO = SAT || (DIRECT && STAGE == 2);
-    t.i0 = base + 2 * tid;
-    t.v0 = t.i0 < a.n;
-    t.v1 = t.i0 + 1 < a.n;
-    load2(a.r.rr, t.i0, t.rr);
-    load2(a.r.mm, t.i0, t.mm);
-    load2(a.r.kk, t.i0, t.kk);
-    load2(a.r.ll, t.i0, t.ll);
-    if (DEPOSIT || SAT || (DIRECT && STAGE == 2)) load2(a.r.dens, t.i0, t.dens);
+    const long long i0 = base + 2 * tid;
+    t.off = (unsigned int)(i0 * 8);
+    t.v0 = i0 < a.n;
+    t.v1 = i0 + 1 < a.n;
+    load2(a.r.rr, t.off, t.rr);
+    load2(a.r.mm, t.off, t.mm);
+    load2(a.r.kk, t.off, t.kk);
+    load2(a.r.ll, t.off, t.ll);
+    if (DEPOSIT || SAT || (DIRECT && STAGE == 2)) load2(a.r.dens, t.off, t.dens);
     if (DEPOSIT) {
-        load2(a.r.drr, t.i0, t.drr);
-        load2(a.r.vol, t.i0, t.vol);
+        load2(a.r.drr, t.off, t.drr);
+        load2(a.r.vol, t.off, t.vol);
     }
-    if (FVEC) load2(a.r.fray, t.i0, t.ff);
-    if (NEED_RHO) load2(a.r.pvf, t.i0, t.pvf);
+    if (FVEC) load2(a.r.fray, t.off, t.ff);
+    if (NEED_RHO) load2(a.r.pvf, t.off, t.pvf);
     if (STAGE == 1 || STAGE == 2) {
-        load2(a.r.q_rr, t.i0, t.qr);
-        load2(a.r.q_mm, t.i0, t.qm);
-        if (SAT) load2(a.r.q_dens, t.i0, t.qd);
+        load2(a.r.q_rr, t.off, t.qr);
+        load2(a.r.q_mm, t.off, t.qm);
+        if (SAT) load2(a.r.q_dens, t.off, t.qd);
     }
     if (DIRECT && STAGE == 2) {
-        load2(a.r.rr0, t.i0, t.rr0);
-        load2(a.r.mm0, t.i0, t.mm0);
+        load2(a.r.rr0, t.off, t.rr0);
+        load2(a.r.mm0, t.off, t.mm0);
     }
 }
 
-// PREFETCH: keep a second register set and issue tile t+1's loads before tile t's math
-// (costs ~50 VGPRs, i.e. occupancy); without it a workgroup relies on the other resident
-// workgroups to cover its load latency.  Picked per launch by the host (MSGW_PREFETCH).
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool PREFETCH, int NH = 2,
-          bool GROUPRED = false>
-__global__ void __launch_bounds__(BLOCK, PREFETCH ? 4 : 1) k_ray_stage(const StageArgs a)
+// LDS views shared by the stage kernels
+struct StageLds {
+    const double4 *sh;      // [ni] {dudz, slope, dvdz, slope}
+    const double2 *rho2;    // [nc] {rhobar, slope}
+    const double *xg, *gs;  // abscissae: grid[1:-1] [ni], grids [nc]
+    double *rows;           // [WAVES][2][ncp] per-wave flux rows
+};
+
+// NOTE: the kernel-argument structs are passed BY VALUE into these inlined helpers.  By
+// reference (a pointer into the kernarg segment) hipcc no longer keeps the fields in SGPRs and
+// the ray-stage kernel grows from 106 to 146 VGPRs (occupancy 4 -> 3).
+// All tiles of this workgroup for one RK stage: physics + RK update + deposit (steps 2-3 of the
+// kernel description in DESIGN.md).  `cur` holds the first tile's registers (already loaded);
+// the shear/rho tables must be staged and the wave rows zeroed.  Ends with the wave's register
+// accumulators folded into its LDS row.
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH>
+__device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds L, TileRegs &cur,
+                                              long long tile0, int tid, int wave, int lane,
+                                              int &wmin, int &wmax)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
-    constexpr bool NEED_RHO = SAT || (DIRECT && STAGE == 2);
-    // LDS: [sh: ni x {dudz, slu, dvdz, slv}] [rho2: nc x {rhobar, slope}] [xg: ni] [gs: nc] [rows] [rng]
-    double4 *s_sh = reinterpret_cast<double4 *>(lds);
-    double2 *s_rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);          // (NEED_RHO)
-    double *s_xg = lds + 4 * ni + 2 * nc;
-    double *s_gs = s_xg + ni;                                // [nc]   (DEPOSIT or NEED_RHO)
-    double *s_rows = s_gs + nc;                              // [WAVES][2][ncp] (DEPOSIT)
-    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * 2 * ncp);
-    // prologue scratch aliases the per-wave rows (zeroed afterwards): F [2][ng], u, v [nc], du, dv [ni]
-    double *s_F = s_rows, *s_u = s_F + 2 * ng, *s_v = s_u + nc, *s_du = s_v + nc, *s_dv = s_du + ni;
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
-
-    MSGW_STAMP_AT(0);
-    // Load order matters (vmcnt retires in order): first the handful of loads of the pending
-    // mean-flow update, THEN the first tile's ray loads, so that the column math below runs
-    // while the ray data is still in flight.  (Host guarantees 2*ncp <= BLOCK and nc <= BLOCK
-    // and col_nrows <= FUSE_ROWS whenever col_pending is set.)
-    const bool fuse = DEPOSIT && a.col_pending;
-    const int ncols = 2 * ncp;
-    double prow[FUSE_ROWS];
-    double c_u = 0, c_v = 0, c_qu = 0, c_qv = 0, c_rho = 1, c_pg0 = 0, c_pg1 = 0;
-    if (fuse) {
-        const int col = min(tid, ncols - 1), jc = min(tid, nc - 1);
-#pragma unroll
-        for (int u = 0; u < FUSE_ROWS; ++u)
-            prow[u] = a.col_rows[(size_t)min(u, a.col_nrows - 1) * ncols + col];
-        c_u = a.cin.uu[jc]; c_v = a.cin.vv[jc];
-        c_qu = a.cin.q_uu[jc]; c_qv = a.cin.q_vv[jc];
-        c_rho = a.c.rhobar[jc]; c_pg0 = a.pg[jc]; c_pg1 = a.pg[nc + jc];
-    }
-    TileRegs cur, nxt;
-    load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, tile0 * (long long)TILE, tid);
-
-    for (int i = tid; i < ni; i += BLOCK) s_xg[i] = a.c.xg[i];
-    if (fuse) {
-        // (1) finish the flux reduction: add the dense rows in row order
-        if (tid < ncols) {
-            double tot = 0.0;
-#pragma unroll
-            for (int u = 0; u < FUSE_ROWS; ++u) tot = tot + ((u < a.col_nrows) ? prow[u] : 0.0);
-            const int p = tid / ncp, c = tid - p * ncp;
-            s_F[p * ng + 1 + c] = tot;                       // pm_flux[:, 1:-1]  (:654)
-        }
-        __syncthreads();
-        column_flux_ends(tid, ng, s_F);
-        __syncthreads();
-        // (2) RK stage of uu, vv (:665-666, :693-698); workgroup 0 publishes the new column
-        if (tid < nc) {
-            double du, dv, un, vn, qu, qv;
-            column_tendency(tid, ng, a.f0, a.dzg, 0, s_F, c_rho, c_pg0, c_pg1, c_u, c_v, du, dv);
-            column_rk(a.col_stage, a.dt, du, dv, c_u, c_v, c_qu, c_qv, un, vn, qu, qv);
-            s_u[tid] = un; s_v[tid] = vn;
-            if (blockIdx.x == 0) { a.cout.uu[tid] = un; a.cout.vv[tid] = vn; a.cout.q_uu[tid] = qu; a.cout.q_vv[tid] = qv; }
-        }
-        __syncthreads();
-        // (3) shear + np.interp slopes straight into the packed LDS table
-        column_shear(tid, BLOCK, ng, a.dzg, s_u, s_v, s_du, s_dv);
-        __syncthreads();
-        for (int i = tid; i < ni; i += BLOCK) {
-            const bool in = i < ni - 1;
-            s_sh[i] = make_double4(s_du[i], in ? column_slope(s_du, s_xg, i) : 0.0,
-                                   s_dv[i], in ? column_slope(s_dv, s_xg, i) : 0.0);
-        }
-        __syncthreads();                                     // scratch is re-used as the wave rows below
-    } else {
-        for (int i = tid; i < ni; i += BLOCK) {
-            const bool in = i < ni - 1;                      // the last point has no slope (never used)
-            s_sh[i] = make_double4(a.c.dudz[i], in ? a.c.slu[i] : 0.0, a.c.dvdz[i], in ? a.c.slv[i] : 0.0);
-        }
-    }
-    if (DEPOSIT || NEED_RHO)
-        for (int i = tid; i < nc; i += BLOCK) s_gs[i] = a.c.grids[i];
-    if (NEED_RHO)
-        for (int i = tid; i < nc; i += BLOCK)
-            s_rho2[i] = make_double2(a.c.rhobar[i], (i < nc - 1) ? a.c.slrho[i] : 0.0);
-    if (DEPOSIT)
-        for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) s_rows[i] = 0.0;
-    __syncthreads();
-    MSGW_STAMP_AT(1);
-
-    int wmin = INT_MAX, wmax = INT_MIN;
+    const double4 *s_sh = L.sh;
+    const double2 *s_rho2 = L.rho2;
+    const double *s_xg = L.xg, *s_gs = L.gs;
+    double *s_rows = L.rows;
+    (void)s_rho2; (void)ng;
     double acc[2][NH > 0 ? NH : 1];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -579,9 +517,7 @@ __global__ void __launch_bounds__(BLOCK, PREFETCH ? 4 : 1) k_ray_stage(const Sta
         const long long base = (tile0 + t) * (long long)TILE;
         if (base >= a.n) break;                              // workgroup-uniform
         const bool more = (t + 1 < a.tiles_per_block) && (base + TILE < a.n);
-        if (PREFETCH && more)                                // next tile's loads fly during this tile's math
-            load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(nxt, a, base + TILE, tid);
-        const long long i0 = cur.i0;
+        const unsigned int i0 = cur.off;                     // byte offset shared by all arrays
         const bool v0 = cur.v0, v1 = cur.v1;
         const bool valid[2] = {v0, v1};
         double (&rr)[2] = cur.rr, (&mm)[2] = cur.mm, (&kk)[2] = cur.kk, (&ll)[2] = cur.ll;
@@ -692,13 +628,106 @@ __global__ void __launch_bounds__(BLOCK, PREFETCH ? 4 : 1) k_ray_stage(const Sta
             deposit_tile<2, NH>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok,
                                 s_rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
         MSGW_STAMP_AT(3 + 2 * (t & 1));
-        if (more) {
-            if (PREFETCH) cur = nxt;
-            else load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, base + TILE, tid);
+        if (more) load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, base + TILE, tid);
+    }
+    if (DEPOSIT) flush_acc<2, NH>(s_rows + wave * 2 * ncp, ncp, lane, acc);
+}
+
+// (A register double-buffered "prefetch next tile" variant was measured and dropped: its ~50
+// extra VGPRs cost a wave of occupancy, capping it at 128 VGPRs spilled, and every spill reload
+// carries s_waitcnt vmcnt(0), which drains the prefetch.  The other resident workgroups cover
+// a workgroup's load latency instead.)
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH = 2, bool GROUPRED = false>
+__global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
+    constexpr bool NEED_RHO = SAT || (DIRECT && STAGE == 2);
+    // LDS: [sh: ni x {dudz, slu, dvdz, slv}] [rho2: nc x {rhobar, slope}] [xg: ni] [gs: nc] [rows] [rng]
+    double4 *s_sh = reinterpret_cast<double4 *>(lds);
+    double2 *s_rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);          // (NEED_RHO)
+    double *s_xg = lds + 4 * ni + 2 * nc;
+    double *s_gs = s_xg + ni;                                // [nc]   (DEPOSIT or NEED_RHO)
+    double *s_rows = s_gs + nc;                              // [WAVES][2][ncp] (DEPOSIT)
+    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * 2 * ncp);
+    // prologue scratch aliases the per-wave rows (zeroed afterwards): F [2][ng], u, v [nc], du, dv [ni]
+    double *s_F = s_rows, *s_u = s_F + 2 * ng, *s_v = s_u + nc, *s_du = s_v + nc, *s_dv = s_du + ni;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
+
+    MSGW_STAMP_AT(0);
+    // Load order matters (vmcnt retires in order): first the handful of loads of the pending
+    // mean-flow update -- summed right away (about one L2 latency; holding 16 row registers
+    // across the ray-load issue costs a wave of occupancy) -- THEN the first tile's ray loads,
+    // so that the column math below runs while the ray data is in flight.  (Host guarantees
+    // 2*ncp <= BLOCK, nc <= BLOCK and col_nrows <= FUSE_ROWS whenever col_pending is set.)
+    const bool fuse = DEPOSIT && a.col_pending;
+    const int ncols = 2 * ncp;
+    double c_tot = 0.0, c_u = 0, c_v = 0, c_qu = 0, c_qv = 0, c_rho = 1, c_pg0 = 0, c_pg1 = 0;
+    if (fuse) {
+        const int col = min(tid, ncols - 1), jc = min(tid, nc - 1);
+        double prow[FUSE_ROWS];
+#pragma unroll
+        for (int u = 0; u < FUSE_ROWS; ++u)
+            prow[u] = a.col_rows[(size_t)min(u, a.col_nrows - 1) * ncols + col];
+        c_u = a.cin.uu[jc]; c_v = a.cin.vv[jc];
+        c_qu = a.cin.q_uu[jc]; c_qv = a.cin.q_vv[jc];
+        c_rho = a.c.rhobar[jc]; c_pg0 = a.pg[jc]; c_pg1 = a.pg[nc + jc];
+#pragma unroll
+        for (int u = 0; u < FUSE_ROWS; ++u) c_tot = c_tot + ((u < a.col_nrows) ? prow[u] : 0.0);   // row order
+    }
+    TileRegs cur;
+    load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, tile0 * (long long)TILE, tid);
+
+    for (int i = tid; i < ni; i += BLOCK) s_xg[i] = a.c.xg[i];
+    if (fuse) {
+        // (1) finish the flux reduction
+        if (tid < ncols) {
+            const int p = tid / ncp, c = tid - p * ncp;
+            s_F[p * ng + 1 + c] = c_tot;                     // pm_flux[:, 1:-1]  (:654)
+        }
+        __syncthreads();
+        column_flux_ends(tid, ng, s_F);
+        __syncthreads();
+        // (2) RK stage of uu, vv (:665-666, :693-698); workgroup 0 publishes the new column
+        if (tid < nc) {
+            double du, dv, un, vn, qu, qv;
+            column_tendency(tid, ng, a.f0, a.dzg, 0, s_F, c_rho, c_pg0, c_pg1, c_u, c_v, du, dv);
+            column_rk(a.col_stage, a.dt, du, dv, c_u, c_v, c_qu, c_qv, un, vn, qu, qv);
+            s_u[tid] = un; s_v[tid] = vn;
+            if (blockIdx.x == 0) { a.cout.uu[tid] = un; a.cout.vv[tid] = vn; a.cout.q_uu[tid] = qu; a.cout.q_vv[tid] = qv; }
+        }
+        __syncthreads();
+        // (3) shear + np.interp slopes straight into the packed LDS table
+        column_shear(tid, BLOCK, ng, a.dzg, s_u, s_v, s_du, s_dv);
+        __syncthreads();
+        for (int i = tid; i < ni; i += BLOCK) {
+            const bool in = i < ni - 1;
+            s_sh[i] = make_double4(s_du[i], in ? column_slope(s_du, s_xg, i) : 0.0,
+                                   s_dv[i], in ? column_slope(s_dv, s_xg, i) : 0.0);
+        }
+        __syncthreads();                                     // scratch is re-used as the wave rows below
+    } else {
+        for (int i = tid; i < ni; i += BLOCK) {
+            const bool in = i < ni - 1;                      // the last point has no slope (never used)
+            s_sh[i] = make_double4(a.c.dudz[i], in ? a.c.slu[i] : 0.0, a.c.dvdz[i], in ? a.c.slv[i] : 0.0);
         }
     }
+    if (DEPOSIT || NEED_RHO)
+        for (int i = tid; i < nc; i += BLOCK) s_gs[i] = a.c.grids[i];
+    if (NEED_RHO)
+        for (int i = tid; i < nc; i += BLOCK)
+            s_rho2[i] = make_double2(a.c.rhobar[i], (i < nc - 1) ? a.c.slrho[i] : 0.0);
+    if (DEPOSIT)
+        for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) s_rows[i] = 0.0;
+    __syncthreads();
+    MSGW_STAMP_AT(1);
+
+    int wmin = INT_MAX, wmax = INT_MIN;
+    const StageLds L{s_sh, s_rho2, s_xg, s_gs, s_rows};
+    process_tiles<STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH>(a, L, cur, tile0, tid, wave, lane, wmin, wmax);
     if (DEPOSIT) {
-        flush_acc<2, NH>(s_rows + wave * 2 * ncp, ncp, lane, acc);
         if (GROUPRED) flush_rows_group<2>(s_rows, ncp, s_rng, lds /* interp tables are dead by now */, tid, a);
         else flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
     }
@@ -736,8 +765,8 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = (tile0 + t) * (long long)TILE;
         if (base >= a.n) break;
-        const long long i0 = base + 2 * tid;
-        const bool v0 = i0 < a.n, v1 = i0 + 1 < a.n;
+        const long long e0 = base + 2 * tid;
+        const unsigned int i0 = (unsigned int)(e0 * 8);
         double rr[2], mm[2], kk[2], ll[2], dens[2], ff[2], pvf[2];
         load2(a.r.rr, i0, rr);
         load2(a.r.mm, i0, mm);
@@ -843,8 +872,9 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = (tile0 + t) * (long long)TILE;
         if (base >= a.n) break;
-        const long long i0 = base + 2 * tid;
-        const bool v0 = i0 < a.n, v1 = i0 + 1 < a.n;
+        const long long e0 = base + 2 * tid;
+        const unsigned int i0 = (unsigned int)(e0 * 8);
+        const bool v0 = e0 < a.n, v1 = e0 + 1 < a.n;
         const bool valid[2] = {v0, v1};
         double kk[2], ll[2], dens[2], vol[2], ff[2], lo[2], up[2], mmid[2];
         if (EXPL) {

@@ -99,15 +99,14 @@ int main(int argc, char **argv)
     timeit("stream 7r+4w", [&] { hipLaunchKernelGGL((k_stream<7, 4>), dim3(blocks), dim3(BLOCK), 0, st, n, (int)tpb, din, dout); }, n * 88.0);
     timeit("stream 9r+4w", [&] { hipLaunchKernelGGL((k_stream<9, 4>), dim3(blocks), dim3(BLOCK), 0, st, n, (int)tpb, din, dout); }, n * 104.0);
     timeit("stream 9r+2w", [&] { hipLaunchKernelGGL((k_stream<9, 2>), dim3(blocks), dim3(BLOCK), 0, st, n, (int)tpb, din, dout); }, n * 88.0);
-    timeit("stage1 no deposit", [&] { hipLaunchKernelGGL((k_ray_stage<1, false, false, false, false, false>), dim3(blocks), dim3(BLOCK), lds, st, a); }, n * 88.0);
-    timeit("stage1 full", [&] { hipLaunchKernelGGL((k_ray_stage<1, false, false, true, false, false>), dim3(blocks), dim3(BLOCK), lds, st, a); }, n * 104.0);
-    timeit("stage1 full prefetch", [&] { hipLaunchKernelGGL((k_ray_stage<1, false, false, true, false, true>), dim3(blocks), dim3(BLOCK), lds, st, a); }, n * 104.0);
+    timeit("stage1 no deposit", [&] { hipLaunchKernelGGL((k_ray_stage<1, false, false, false, false>), dim3(blocks), dim3(BLOCK), lds, st, a); }, n * 88.0);
+    timeit("stage1 full", [&] { hipLaunchKernelGGL((k_ray_stage<1, false, false, true, false>), dim3(blocks), dim3(BLOCK), lds, st, a); }, n * 104.0);
 #ifdef MSGW_STAMP
     {   // phase timeline of one launch of the full stage-1 kernel (wall_clock64 = 100 MHz)
         unsigned long long *dst; CK(hipMalloc(&dst, (size_t)blocks * 8 * sizeof(unsigned long long)));
         CK(hipMemset(dst, 0, (size_t)blocks * 8 * sizeof(unsigned long long)));
         StageArgs b = a; b.stamps = dst;
-        for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL((k_ray_stage<1, false, false, true, false, false>), dim3(blocks), dim3(BLOCK), lds, st, b); }
+        for (int rep = 0; rep < 3; ++rep) { hipLaunchKernelGGL((k_ray_stage<1, false, false, true, false>), dim3(blocks), dim3(BLOCK), lds, st, b); }
         hipStreamSynchronize(st);
         std::vector<unsigned long long> hs((size_t)blocks * 8);
         CK(hipMemcpy(hs.data(), dst, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -124,7 +123,7 @@ int main(int argc, char **argv)
         }
     }
 #endif
-    timeit("stage0 full", [&] { hipLaunchKernelGGL((k_ray_stage<0, false, false, true, false, false>), dim3(blocks), dim3(BLOCK), lds, st, a); }, n * 88.0);
-    timeit("stage2 full", [&] { hipLaunchKernelGGL((k_ray_stage<2, false, false, true, false, false>), dim3(blocks), dim3(BLOCK), lds, st, a); }, n * 88.0);
+    timeit("stage0 full", [&] { hipLaunchKernelGGL((k_ray_stage<0, false, false, true, false>), dim3(blocks), dim3(BLOCK), lds, st, a); }, n * 88.0);
+    timeit("stage2 full", [&] { hipLaunchKernelGGL((k_ray_stage<2, false, false, true, false>), dim3(blocks), dim3(BLOCK), lds, st, a); }, n * 88.0);
     return 0;
 }
