@@ -190,27 +190,27 @@ __device__ __forceinline__ void persist_column(const PersistArgs p, const Persis
 
 template <int STAGE, bool SAT, bool FVEC, bool DIRECT>
 __device__ __forceinline__ bool persist_stage(const PersistArgs p, const PersistLds L, unsigned int q,
-                                              long long tile0, int tid, int wave, int lane)
+                                              long long start, long long end, int tid, int wave, int lane)
 {
     const StageArgs a = p.s;
     const int ncp = a.ng - 2;
     // Opaque copies: without them the three inlined stage bodies share (CSE) every per-array tile
     // address and keep ~60 VGPRs of 64-bit addresses alive across the whole step.
-    asm volatile("" : "+s"(tile0));
+    asm volatile("" : "+s"(start));
     asm volatile("" : "+v"(tid));
     TileRegs cur;
     // wave 0 polls and fences (its acquire waits for its own outstanding loads), so it loads after
-    if (wave != 0 || q == 0) load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, tile0 * (long long)TILE, tid);
+    if (wave != 0 || q == 0) load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, start, tid, end);
     if (q > 0) {
         if (!persist_wait(p, q, L.flag, tid)) return false;
-        if (wave == 0) load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, tile0 * (long long)TILE, tid);
+        if (wave == 0) load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, start, tid, end);
         persist_column(p, L, q, (STAGE + 2) % 3, tid);
     }
     for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
     __syncthreads();
     int wmin = INT_MAX, wmax = INT_MIN;
     const StageLds SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
-    process_tiles<STAGE, SAT, FVEC, true, DIRECT, 2>(a, SL, cur, tile0, tid, wave, lane, wmin, wmax);
+    process_tiles<STAGE, SAT, FVEC, true, DIRECT, 2>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax);
     persist_publish(p, L.rows, ncp, L.flag, tid, q);
     return true;
 }
@@ -233,7 +233,8 @@ __global__ void __launch_bounds__(BLOCK) k_rk3_persist(const PersistArgs p)
     L.F = L.rows; L.u = L.F + 2 * ng; L.v = L.u + nc; L.du = L.v + nc; L.dv = L.du + ni;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
+    const long long start = (long long)blockIdx.x * a.rays_per_block;
+    const long long end = min(a.n, start + a.rays_per_block);
 
     for (int i = tid; i < ni; i += BLOCK) L.xg[i] = a.c.xg[i];
     for (int i = tid; i < nc; i += BLOCK) {
@@ -254,11 +255,11 @@ __global__ void __launch_bounds__(BLOCK) k_rk3_persist(const PersistArgs p)
 
     unsigned int q = 0;
     for (int step = 0; step < p.nsteps; ++step) {
-        if (!persist_stage<0, SAT, FVEC, DIRECT>(p, L, q, tile0, tid, wave, lane)) return;
+        if (!persist_stage<0, SAT, FVEC, DIRECT>(p, L, q, start, end, tid, wave, lane)) return;
         ++q;
-        if (!persist_stage<1, SAT, FVEC, DIRECT>(p, L, q, tile0, tid, wave, lane)) return;
+        if (!persist_stage<1, SAT, FVEC, DIRECT>(p, L, q, start, end, tid, wave, lane)) return;
         ++q;
-        if (!persist_stage<2, SAT, FVEC, DIRECT>(p, L, q, tile0, tid, wave, lane)) return;
+        if (!persist_stage<2, SAT, FVEC, DIRECT>(p, L, q, start, end, tid, wave, lane)) return;
         ++q;
     }
     if (blockIdx.x != 0) return;

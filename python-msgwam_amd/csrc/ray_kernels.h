@@ -39,7 +39,9 @@ struct ColPtrs {
 struct StageArgs {
     long long n;
     int ng;
-    int tiles_per_block;
+    int tiles_per_block;  // ceil(rays_per_block / TILE)
+    long long rays_per_block;   // contiguous rays owned by a workgroup (multiple of 16: 128-B aligned
+                          // starts); chosen so that the workgroups divide evenly over the CUs
     double dt;
     double bvf2;          // bvf**2
     double f_uni;         // per-ray f when it is the same for every ray
@@ -114,6 +116,28 @@ __device__ __forceinline__ double wave_sum(double v)
     const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16);
     const double r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
     return (r0 + r1) + (r2 + r3);
+}
+// Two sums at once (the two pseudo-momentum-flux components): v_permlane32_swap puts the
+// half-sums of `a` in lanes 0-31 and those of `b` in lanes 32-63, four DPP steps reduce inside
+// each 16-lane row, v_permlane16_swap adds the two rows of each half.  32 instructions for both
+// sums instead of ~40 each; fixed order, bit-reproducible.  All 64 lanes must be active.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void wave_sum2(double a, double b, double &ta, double &tb)
+{
+    const u32x2_t lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    // {a.lanes0-31, b.lanes0-31} + {a.lanes32-63, b.lanes32-63}
+    double v = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+    v = v + dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v = v + dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v = v + dpp_f64<0x141>(v);    // row_half_mirror
+    v = v + dpp_f64<0x140>(v);    // row_mirror: every lane of a row holds the row sum
+    const u32x2_t rlo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const u32x2_t rhi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    // {r0, r0, r2, r2} + {r1, r1, r3, r3}: rows 0,1 belong to `a`, rows 2,3 to `b`
+    v = __hiloint2double((int)rhi.x, (int)rlo.x) + __hiloint2double((int)rhi.y, (int)rlo.y);
+    ta = readlane_f64(v, 0);
+    tb = readlane_f64(v, 32);
 }
 __device__ __forceinline__ int wave_min(int v)
 {
@@ -275,13 +299,12 @@ __device__ __forceinline__ void deposit_tile(const double (&lo)[RPT], const doub
 #pragma unroll
                 for (int p = 0; p < NP; ++p) s[p] = s[p] + (in ? wv * pay[p][r] : 0.0);
             }
+            double tsum[NP];
+            if (NP == 2) wave_sum2(s[0], s[NP - 1], tsum[0], tsum[NP - 1]);
+            else tsum[0] = wave_sum(s[0]);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-#if defined(MSGW_ABLATE) && MSGW_ABLATE == 2
-                const double t = s[p];
-#else
-                const double t = wave_sum(s[p]);
-#endif
+                const double t = tsum[p];
                 if (NH > 0) {
                     const double mine = (lane == (c & 63)) ? t : 0.0;
 #pragma unroll
@@ -453,13 +476,16 @@ struct TileRegs {
 };
 
 template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
-__device__ __forceinline__ void load_tile(TileRegs &t, const StageArgs a, long long base, int tid)
+__device__ __forceinline__ void load_tile(TileRegs &t, const StageArgs a, long long base, int tid,
+                                          long long end)
 {
+    // Loads are unconditional (the arrays are padded by a tile); rays at or beyond `end` belong to
+    // the next workgroup or to the padding: they are computed on but neither deposited nor stored.
     constexpr bool NEED_RHO = SAT || (DIRECT && STAGE == 2);
     const long long i0 = base + 2 * tid;
     t.off = (unsigned int)(i0 * 8);
-    t.v0 = i0 < a.n;
-    t.v1 = i0 + 1 < a.n;
+    t.v0 = i0 < end;
+    t.v1 = i0 + 1 < end;
     load2(a.r.rr, t.off, t.rr);
     load2(a.r.mm, t.off, t.mm);
     load2(a.r.kk, t.off, t.kk);
@@ -499,8 +525,8 @@ struct StageLds {
 // accumulators folded into its LDS row.
 template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH>
 __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds L, TileRegs &cur,
-                                              long long tile0, int tid, int wave, int lane,
-                                              int &wmin, int &wmax)
+                                              long long start, long long end, int tid, int wave,
+                                              int lane, int &wmin, int &wmax)
 {
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
     const double4 *s_sh = L.sh;
@@ -514,9 +540,9 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
 #pragma unroll
         for (int h = 0; h < (NH > 0 ? NH : 1); ++h) acc[p][h] = 0.0;
     for (int t = 0; t < a.tiles_per_block; ++t) {
-        const long long base = (tile0 + t) * (long long)TILE;
-        if (base >= a.n) break;                              // workgroup-uniform
-        const bool more = (t + 1 < a.tiles_per_block) && (base + TILE < a.n);
+        const long long base = start + (long long)t * TILE;
+        if (base >= end) break;                              // workgroup-uniform
+        const bool more = (t + 1 < a.tiles_per_block) && (base + TILE < end);
         const unsigned int i0 = cur.off;                     // byte offset shared by all arrays
         const bool v0 = cur.v0, v1 = cur.v1;
         const bool valid[2] = {v0, v1};
@@ -524,7 +550,7 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
         double (&dens)[2] = cur.dens, (&drr)[2] = cur.drr, (&vol)[2] = cur.vol, (&ff)[2] = cur.ff;
         double (&pvf)[2] = cur.pvf, (&qr)[2] = cur.qr, (&qm)[2] = cur.qm, (&qd)[2] = cur.qd;
         double (&rr0)[2] = cur.rr0, (&mm0)[2] = cur.mm0;
-        if (DIRECT && STAGE == 0) {                          // keep the start-of-step rr, mm
+        if (DIRECT && STAGE == 0 && v0) {                    // keep the start-of-step rr, mm
             store2(a.r.rr0, i0, rr);
             store2(a.r.mm0, i0, mm);
         }
@@ -610,25 +636,27 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
         asm volatile("" :: "v"(nrr[0]), "v"(nmm[1]));
         MSGW_STAMP_AT(2 + 2 * (t & 1));
 #endif
-        if (STAGE == 3) {
-            store2(a.r.q_rr, i0, nrr);
-            store2(a.r.q_mm, i0, nmm);
-            store2(a.r.q_dens, i0, ndens);
-        } else {
-            store2(a.r.rr, i0, nrr);
-            store2(a.r.mm, i0, nmm);
-            if (SAT || (DIRECT && STAGE == 2)) store2(a.r.dens, i0, ndens);
-            if (STAGE != 2) {
-                store2(a.r.q_rr, i0, qr);
-                store2(a.r.q_mm, i0, qm);
-                if (SAT) store2(a.r.q_dens, i0, qd);
+        if (v0) {                                            // only the owner stores (pairs never straddle)
+            if (STAGE == 3) {
+                store2(a.r.q_rr, i0, nrr);
+                store2(a.r.q_mm, i0, nmm);
+                store2(a.r.q_dens, i0, ndens);
+            } else {
+                store2(a.r.rr, i0, nrr);
+                store2(a.r.mm, i0, nmm);
+                if (SAT || (DIRECT && STAGE == 2)) store2(a.r.dens, i0, ndens);
+                if (STAGE != 2) {
+                    store2(a.r.q_rr, i0, qr);
+                    store2(a.r.q_mm, i0, qm);
+                    if (SAT) store2(a.r.q_dens, i0, qd);
+                }
             }
         }
         if (DEPOSIT)
             deposit_tile<2, NH>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok,
                                 s_rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
         MSGW_STAMP_AT(3 + 2 * (t & 1));
-        if (more) load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, base + TILE, tid);
+        if (more) load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, base + TILE, tid, end);
     }
     if (DEPOSIT) flush_acc<2, NH>(s_rows + wave * 2 * ncp, ncp, lane, acc);
 }
@@ -654,7 +682,8 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
     double *s_F = s_rows, *s_u = s_F + 2 * ng, *s_v = s_u + nc, *s_du = s_v + nc, *s_dv = s_du + ni;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
+    const long long start = (long long)blockIdx.x * a.rays_per_block;
+    const long long end = min(a.n, start + a.rays_per_block);
 
     MSGW_STAMP_AT(0);
     // Load order matters (vmcnt retires in order): first the handful of loads of the pending
@@ -678,7 +707,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
         for (int u = 0; u < FUSE_ROWS; ++u) c_tot = c_tot + ((u < a.col_nrows) ? prow[u] : 0.0);   // row order
     }
     TileRegs cur;
-    load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, tile0 * (long long)TILE, tid);
+    load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, start, tid, end);
 
     for (int i = tid; i < ni; i += BLOCK) s_xg[i] = a.c.xg[i];
     if (fuse) {
@@ -726,7 +755,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
 
     int wmin = INT_MAX, wmax = INT_MIN;
     const StageLds L{s_sh, s_rho2, s_xg, s_gs, s_rows};
-    process_tiles<STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH>(a, L, cur, tile0, tid, wave, lane, wmin, wmax);
+    process_tiles<STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH>(a, L, cur, start, end, tid, wave, lane, wmin, wmax);
     if (DEPOSIT) {
         if (GROUPRED) flush_rows_group<2>(s_rows, ncp, s_rng, lds /* interp tables are dead by now */, tid, a);
         else flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
@@ -761,12 +790,14 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
         }
     __syncthreads();
 
-    const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
+    const long long start = (long long)blockIdx.x * a.rays_per_block;
+    const long long end = min(a.n, start + a.rays_per_block);
     for (int t = 0; t < a.tiles_per_block; ++t) {
-        const long long base = (tile0 + t) * (long long)TILE;
-        if (base >= a.n) break;
+        const long long base = start + (long long)t * TILE;
+        if (base >= end) break;
         const long long e0 = base + 2 * tid;
         const unsigned int i0 = (unsigned int)(e0 * 8);
+        const bool own = e0 < end;
         double rr[2], mm[2], kk[2], ll[2], dens[2], ff[2], pvf[2];
         load2(a.r.rr, i0, rr);
         load2(a.r.mm, i0, mm);
@@ -830,9 +861,11 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
                 if (maxd < dens[r] * pvf[r]) dens[r] = maxd;
             }
         }
-        store2(a.r.rr, i0, rr);
-        store2(a.r.mm, i0, mm);
-        if (NEED_RHO) store2(a.r.dens, i0, dens);
+        if (own) {
+            store2(a.r.rr, i0, rr);
+            store2(a.r.mm, i0, mm);
+            if (NEED_RHO) store2(a.r.dens, i0, dens);
+        }
     }
 }
 

@@ -38,7 +38,7 @@ int main(int argc, char **argv)
     const int bpc = argc > 2 ? atoi(argv[2]) : 4;
     hipStream_t st; CK(hipStreamCreate(&st));
     std::vector<double *> buf(16);
-    for (auto &p : buf) { CK(hipMalloc(&p, (n + 2) * sizeof(double))); }
+    for (auto &p : buf) { CK(hipMalloc(&p, (n + 2 * TILE) * sizeof(double))); }
     // synthetic z-major spectrum-like state
     std::vector<double> h(n);
     auto up = [&](double *d, auto f) { for (long long i = 0; i < n; ++i) h[i] = f(i); return hipMemcpy(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice); };
@@ -71,7 +71,7 @@ int main(int argc, char **argv)
     double *partial; int *ranges;
     CK(hipMalloc(&partial, (size_t)blocks * 2 * (ng - 2) * 8)); CK(hipMalloc(&ranges, blocks * 8));
     StageArgs a{};
-    a.n = n; a.ng = ng; a.tiles_per_block = (int)tpb; a.dt = 120.0; a.bvf2 = 1e-4; a.f_uni = 0; a.f0sq = 0; a.same_f = 1;
+    a.n = n; a.ng = ng; a.tiles_per_block = (int)tpb; a.rays_per_block = tpb * TILE; a.dt = 120.0; a.bvf2 = 1e-4; a.f_uni = 0; a.f0sq = 0; a.same_f = 1;
     a.sat_c = .5; a.sat_rr_div = 120.0; a.xg0 = 1000.0; a.inv_dzg = 1e-3; a.gs0 = 500.0; a.xg_last = 99000.0; a.gs_last = 99500.0; a.inv_dzs = 1.0 / 1000.0; a.dzs = 1000.0; a.mk_ok = 1;
     a.r = RayPtrs{dens, rr, mm, drr, kk, ll, dmm, vol, fray, pvf, q_rr, q_mm, q_dens, rr0, mm0};
     a.c = ColPtrs{col + 1, col + 2 * ng, col + 3 * ng, col + 4 * ng, col + 5 * ng, col + ng, col + 6 * ng, col + 7 * ng};
