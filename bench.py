@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=int(os.environ.get("MSGW_BLOCKS_PER_CU", 4)))
     ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("MSGW_GRAPH_STEPS", 4)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-size-sweep", action="store_true", help="skip the extra 4x-rays measurement (N=1 only)")
     ap.add_argument("--kernel-events", choices=["separate", "same", "none"], default="separate",
                     help="where the per-launch HIP-event timing of the dominant kernel is taken")
     args = ap.parse_args()
@@ -125,65 +126,81 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     lprop, grid, grids, uu, vv = column(args.ngrid)
-    n_total = args.rays_per_gpu * world
-    lo, hi = shard_bounds(n_total, world, rank)
-    sp = gaussian_spectrum(n_total, grids, lprop.rhobar, alpha=0.01, start=lo, stop=hi)
-    n_local = hi - lo
-
-    p = _capi.Propagator(args.ngrid, n_local, device=local_rank)
-    p.set_config(0.01, 0.0, 1.0, False)
-    p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, uu, vv)
-    p.upload_rays(sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], sp["phi"],
-                  sp["dkk"], sp["dll"], sp["area"])
-    p.set_tuning(args.blocks_per_cu, args.graph_steps)
-    if world > 1:
-        uid = [_capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        p.comm_init(uid[0], rank, world)
-
     flags = _capi.FIXED_BACKGROUND if args.workload == "fixed" else 0
     same = args.kernel_events == "same"
-    tflags = flags | (_capi.TIME_KERNELS if same else 0)
+    uid = None
+    if world > 1:
+        box = [_capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
 
-    def fence():
-        p.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    def measure(rays_per_gpu, steps, warmup, kernel_events):
+        """One timed region: `steps` RK3 steps of rays_per_gpu rays per rank, state resident."""
+        n_total = rays_per_gpu * world
+        lo, hi = shard_bounds(n_total, world, rank)
+        sp = gaussian_spectrum(n_total, grids, lprop.rhobar, alpha=0.01, start=lo, stop=hi)
+        n_local = hi - lo
+        p = _capi.Propagator(args.ngrid, n_local, device=local_rank)
+        p.set_config(0.01, 0.0, 1.0, False)
+        p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, uu, vv)
+        p.upload_rays(sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], sp["phi"],
+                      sp["dkk"], sp["dll"], sp["area"])
+        p.set_tuning(args.blocks_per_cu, args.graph_steps)
+        if uid is not None:
+            p.comm_init(uid, rank, world)
 
-    p.step(DT, args.warmup, flags)
-    fence()
-    c0 = p.counters()
-    t0 = time.perf_counter()
-    p.step(DT, args.steps, tflags)
-    p.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    c1 = p.counters()
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-
-    # per-launch duration of the dominant kernel (HIP events on the library's own stream)
-    kern_ms = None
-    if args.kernel_events != "none":
-        if not same:
-            p.step(DT, args.steps, flags | _capi.TIME_KERNELS)
+        def fence():
             p.sync()
-            c1 = p.counters()
-        launches = c1["ray_kernel_launches"] - c0["ray_kernel_launches"]
-        kern_ms = (c1["ray_kernel_ms_sum"] - c0["ray_kernel_ms_sum"]) / max(launches, 1)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
 
-    rr_chk = p.download_rays()[1]
-    finite = bool(np.all(np.isfinite(rr_chk)))
+        p.step(DT, warmup, flags)
+        fence()
+        c0 = p.counters()
+        t0 = time.perf_counter()
+        p.step(DT, steps, flags | (_capi.TIME_KERNELS if kernel_events == "same" else 0))
+        fence()
+        wall = time.perf_counter() - t0
+        c1 = p.counters()
+        if dist is not None:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        kern_ms, launches = None, 0
+        if kernel_events != "none":                    # HIP events on the library's own stream
+            if kernel_events != "same":
+                p.step(DT, steps, flags | _capi.TIME_KERNELS)
+                p.sync()
+                c1 = p.counters()
+            launches = c1["ray_kernel_launches"] - c0["ray_kernel_launches"]
+            kern_ms = (c1["ray_kernel_ms_sum"] - c0["ray_kernel_ms_sum"]) / max(launches, 1)
+        finite = bool(np.all(np.isfinite(p.download_rays()[1])))
+        p.close()
+        return dict(n_total=n_total, n_local=n_local, wall=wall, kern_ms=kern_ms, launches=launches,
+                    counters=c1, finite=finite)
+
+    m = measure(args.rays_per_gpu, args.steps, args.warmup, args.kernel_events)
+    n_total, n_local, wall, kern_ms, c1, finite = (m["n_total"], m["n_local"], m["wall"], m["kern_ms"],
+                                                  m["counters"], m["finite"])
+    extra = None
+    if world == 1 and args.workload == "coupled" and not args.no_size_sweep:
+        big = measure(4 * args.rays_per_gpu, max(args.steps // 4, 20), max(args.warmup // 4, 5), "none")
+        v = big["n_total"] * max(args.steps // 4, 20) / big["wall"]
+        extra = {"rays_per_gpu": big["n_total"], "value": v,
+                 "whole_job_hbm_frac": v * BYTES_PER_RAY_STEP["coupled"] / 1e9 / HBM_PEAK_GBS,
+                 "note": "same workload at 4x the rays: the fixed per-stage synchronisation cost amortises"}
 
     if rank == 0:
         value = n_total * args.steps / wall
         bps = BYTES_PER_RAY_STEP[args.workload]
-        per_launch_bytes = bps / LAUNCHES_PER_STEP[args.workload] * n_local
+        persist_steps = c1.get("persist_steps", 0)
+        if persist_steps:        # one persistent launch covers persist_steps RK3 steps (3 stages each)
+            per_launch_bytes = bps * persist_steps * n_local
+            kernel_name = "k_rk3_persist"
+        else:
+            per_launch_bytes = bps / LAUNCHES_PER_STEP[args.workload] * n_local
+            kernel_name = KERNEL_NAME[args.workload]
         roofline = None
         if kern_ms:
             achieved = per_launch_bytes / (kern_ms * 1e-3) / 1e9
@@ -191,10 +208,12 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(f"{args.workload}:{n_local}")
+                    t = json.load(open(tpath)).get(f"{kernel_name}:{n_local}")
+                    if isinstance(t, dict) and persist_steps:      # committed PMC result, scaled to this launch
+                        traffic = t["bytes_per_ray_step"] * n_local * persist_steps
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": KERNEL_NAME[args.workload], "achieved": achieved,
+            roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "kernel_ms_avg": kern_ms,
                         "algorithmic_bytes_per_launch": per_launch_bytes,
@@ -212,15 +231,16 @@ def main():
                        "rays_total": n_total, "rays_per_gpu": args.rays_per_gpu, "ngrid": args.ngrid,
                        "dt": DT, "parallelism": f"rays sharded x{world}, flux all-reduce per RK stage"
                        if world > 1 else "single GPU",
-                       "graph_steps": c1["graph_steps"], "blocks": c1["blocks"]},
+                       "graph_steps": c1["graph_steps"], "persist_steps": persist_steps, "blocks": c1["blocks"]},
             "whole_job_hbm_frac": value * bps / 1e9 / (HBM_PEAK_GBS * world),
             "state_finite": finite,
             "roofline": roofline,
         }
+        if extra is not None:
+            out["larger_problem"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, grid, uu, vv)
         print(json.dumps(out), flush=True)
-    p.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -831,7 +831,9 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
         flags &= ~(MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK);      // raytracer.py:182: only if not online
     HIPCHK(c, hipSetDevice(c->device));
     const bool time_kernels = (flags & MSGW_TIME_KERNELS) != 0;
-    const bool eager = time_kernels || (flags & MSGW_NO_GRAPH) || c->graph_steps == 0;
+    // With a real collective in the chain launches stay eager: hipGraph capture of ncclAllReduce
+    // across ranks cannot be exercised on the 1-GPU development boxes, so it is not relied upon.
+    const bool eager = time_kernels || (flags & MSGW_NO_GRAPH) || c->graph_steps == 0 || c->nranks > 1;
     const unsigned gflags = flags & ~(MSGW_NO_GRAPH | MSGW_TIME_KERNELS);
     if (time_kernels) c->kev_used = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));

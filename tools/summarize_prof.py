@@ -24,7 +24,7 @@ with open(os.path.join(root, "profiles", f"{tag}_summary.md"), "w") as fh:
         fh.write(f"| `{k[:90]}` | {v['calls']} | {v['avg_us']:.2f} | {v['min_us']:.2f} | {v['max_us']:.2f} | {v['pct']:.1f} |\n")
     fh.write("\n## PMC (mean per dispatch)\n\n")
     for k, cs in out["pmc"].items():
-        if "k_ray" not in k and "k_column" not in k and "k_flux" not in k:
+        if "k_ray" not in k and "k_rk3" not in k and "k_column" not in k and "k_flux" not in k:
             continue
         fh.write(f"### `{k[:100]}`\n\n" + "".join(f"- {cn}: {v['mean']:.4g} (n={v['n']})\n" for cn, v in sorted(cs.items())) + "\n")
 print(json.dumps({k: v["avg_us"] for k, v in out["kernels"].items() if "msgw" in k}, indent=1))
