@@ -113,8 +113,11 @@ struct msgw_ctx {
     // persistent RK3 kernel (single rank, coupled)
     int persist = 1;                 // 0 disables (MSGW_PERSIST=0 or after a time-out)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
-    unsigned int *pdone = nullptr;   // [0] done counter, [1] status (as int), [2] ready counter
+    unsigned int *pdone = nullptr;   // [0] ready, [1] status, [2..3] done2, [64..191] group tickets
     double *flux2 = nullptr;         // [2][ncols] final flux rows of the persistent kernel
+    unsigned long long *pstamps = nullptr;   // diagnostic builds only
+    double *grp_part2 = nullptr;     // [2][blocks][row_stride]
+    size_t grp_part2_elems = 0;
 
     // graph
     int graph_steps = 0;
@@ -274,11 +277,20 @@ int ensure_groups(msgw_ctx *c)
         HIPCHK(c, hipMalloc(&c->grp_part, need * sizeof(double)));
         c->grp_part_elems = need;
     }
+    const size_t need2 = (size_t)2 * 2048 * c->row_stride;      // persistent kernel: <= 2048 ray workgroups
+    if (need2 > c->grp_part2_elems) {
+        drop_graph(c);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->grp_part2) HIPCHK(c, hipFree(c->grp_part2));
+        c->grp_part2 = nullptr;
+        HIPCHK(c, hipMalloc(&c->grp_part2, need2 * sizeof(double)));
+        c->grp_part2_elems = need2;
+    }
     if (!c->grp_rows) {
         HIPCHK(c, hipMalloc(&c->grp_rows, sizeof(double) * (size_t)FUSE_ROWS * 2 * (c->ng - 2)));
         HIPCHK(c, hipMalloc(&c->grp_cnt, sizeof(unsigned int) * 64));
         HIPCHK(c, hipMalloc(&c->grp_rows2, sizeof(double) * (size_t)2 * PERSIST_GROUPS * 2 * (c->ng - 2)));
-        HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * 4));
+        HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * 256));
         HIPCHK(c, hipMalloc(&c->flux2, sizeof(double) * (size_t)2 * 2 * (c->ng - 2)));
     }
     HIPCHK(c, hipMemsetAsync(c->grp_cnt, 0, sizeof(unsigned int) * 64, c->stream));
@@ -475,15 +487,17 @@ size_t persist_lds_bytes(int ng)
 }
 
 template <bool SAT, bool FVEC, bool DIRECT>
-int launch_persist_t(msgw_ctx *c, const PersistArgs &pa, bool *resident)
+int launch_persist_t(msgw_ctx *c, PersistArgs &pa, bool *resident)
 {
     auto k = k_rk3_persist<SAT, FVEC, DIRECT>;
     const size_t lds = persist_lds_bytes(c->ng);
     if (int rc = ensure_lds(c, k, lds)) return rc;
     int per_cu = 0;
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, BLOCK, lds));
-    *resident = (long long)per_cu * c->ncu >= c->blocks;       // every workgroup must be co-resident
+    *resident = (long long)per_cu * c->ncu >= c->blocks && c->blocks <= 2048;   // every workgroup co-resident
     if (!*resident) return MSGW_OK;
+    pa.s.grp_size = (c->blocks + PERSIST_GROUPS - 1) / PERSIST_GROUPS;
+    pa.ngroups = (c->blocks + pa.s.grp_size - 1) / pa.s.grp_size;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->time_next) {
         hipEvent_t *ev = timing_events(c);
@@ -505,20 +519,24 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
     PersistArgs pa{};
     pa.s = make_stage_args(c, dt, flags);
-    pa.s.grp_size = (c->blocks + PERSIST_GROUPS - 1) / PERSIST_GROUPS;
-    pa.ngroups = (c->blocks + pa.s.grp_size - 1) / pa.s.grp_size;
     pa.nsteps = count;
     pa.grp_rows2 = c->grp_rows2;
-    pa.done = c->pdone;
-    pa.status = reinterpret_cast<int *>(c->pdone + 1);
-    pa.ready = c->pdone + 2;
+    pa.grp_part2 = c->grp_part2;
     pa.flux2 = c->flux2;
+    pa.ready = c->pdone;
+    pa.status = reinterpret_cast<int *>(c->pdone + 1);
+    pa.done2 = c->pdone + 2;
+    pa.grp_cnt2 = c->pdone + 64;
+#ifdef MSGW_STAMP
+    if (!c->pstamps) HIPCHK(c, hipMalloc(&c->pstamps, sizeof(unsigned long long) * 4096 * PSTAMP_PASSES * 4));
+    HIPCHK(c, hipMemsetAsync(c->pstamps, 0, sizeof(unsigned long long) * 4096 * PSTAMP_PASSES * 4, c->stream));
+    pa.pstamps = c->pstamps;
+#endif
     pa.timeout_ticks = 20000000ull;                            // 0.2 s of wall clock per wait
     pa.cin = ColIn{c->uu, c->vv, c->q_uu, c->q_vv};
     pa.cout = ColOut{c->uu, c->vv, c->q_uu, c->q_vv};
     pa.dudz = c->dudz; pa.dvdz = c->dvdz; pa.slu = c->slu; pa.slv = c->slv;
-    HIPCHK(c, hipMemsetAsync(c->pdone, 0, sizeof(unsigned int) * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->grp_cnt, 0, sizeof(unsigned int) * 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pdone, 0, sizeof(unsigned int) * 256, c->stream));
     bool resident = false;
     c->time_next = time_kernels;
     int rc = MSGW_OK;
@@ -540,8 +558,8 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
         c->persist = 0;
         c->have_rays = false;                                  // the step was abandoned half-way
         return fail(c, MSGW_ERR_HIP, "persistent RK3 kernel timed out waiting for other workgroups "
-                    "(not all %d workgroups resident?); state is invalid, upload the rays again "
-                    "(the per-stage kernels will be used from now on)", c->blocks);
+                    "(not all of them resident?); state is invalid, upload the rays again "
+                    "(the per-stage kernels will be used from now on)");
     }
     return MSGW_OK;
 }
@@ -712,6 +730,7 @@ int msgw_destroy(msgw_ctx *c)
     if (c->grp_rows2) (void)hipFree(c->grp_rows2);
     if (c->pdone) (void)hipFree(c->pdone);
     if (c->flux2) (void)hipFree(c->flux2);
+    if (c->grp_part2) (void)hipFree(c->grp_part2);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1102,6 +1121,16 @@ int msgw_comm_init(msgw_ctx *c, const void *id128, int rank, int nranks)
     drop_graph(c);
     return MSGW_OK;
 }
+
+#ifdef MSGW_STAMP
+// diagnostic build only: copy out the persistent kernel's [workgroups][PSTAMP_PASSES][4] stamps
+int msgw_debug_stamps(msgw_ctx *c, unsigned long long *out, int nblocks)
+{
+    if (!c || !c->pstamps) return MSGW_ERR_ARG;
+    HIPCHK(c, hipMemcpy(out, c->pstamps, sizeof(unsigned long long) * (size_t)nblocks * PSTAMP_PASSES * 4, hipMemcpyDeviceToHost));
+    return MSGW_OK;
+}
+#endif
 
 int msgw_counters(msgw_ctx *c, msgw_counters_t *out)
 {

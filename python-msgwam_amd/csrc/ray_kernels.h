@@ -253,7 +253,7 @@ __device__ __forceinline__ void deposit_indices(double lo, double up, bool valid
 // register h owns level 64*h + L), so the per-level result of the DPP reduction is added with a
 // predicated VALU add instead of a lane-0 LDS read-modify-write; flush_acc() folds them into the
 // wave's LDS row once per workgroup.  NH == 0 (columns with more than 128 levels): LDS RMW.
-#ifdef MSGW_STAMP
+#ifdef MSGW_DBG_LEVELS
 __device__ unsigned long long g_dbg_levels, g_dbg_tiles, g_dbg_wide;
 #endif
 template <int NP, int NH>
@@ -276,7 +276,7 @@ __device__ __forceinline__ void deposit_tile(const double (&lo)[RPT], const doub
     if (whi <= wlo) return;
     wmin = min(wmin, wlo);
     wmax = max(wmax, whi);
-#ifdef MSGW_STAMP
+#ifdef MSGW_DBG_LEVELS
     if (lane == 0) { atomicAdd(&g_dbg_levels, (unsigned long long)(whi - wlo)); atomicAdd(&g_dbg_tiles, 1ull);
                      if (whi - wlo > SPAN_MAX) atomicAdd(&g_dbg_wide, 1ull); }
 #endif
@@ -523,7 +523,11 @@ struct StageLds {
 // kernel description in DESIGN.md).  `cur` holds the first tile's registers (already loaded);
 // the shear/rho tables must be staged and the wave rows zeroed.  Ends with the wave's register
 // accumulators folded into its LDS row.
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH>
+// LAG = true ("lagged deposit", persistent kernel): instead of depositing the stage's INPUT state,
+// deposit the state this stage has just PRODUCED, i.e. the next stage's wave_projection input.
+// Same values (cg_rr is re-evaluated from the same kk, ll, new mm the next stage will load), but the
+// flux of stage q+1 is then published one whole pass before it is needed.
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH, bool LAG = false>
 __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds L, TileRegs &cur,
                                               long long start, long long end, int tid, int wave,
                                               int lane, int &wmin, int &wmax)
@@ -583,7 +587,7 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
                 const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);  // :601
                 if (maxd < dens[r] * pvf[r]) st_dens = (maxd - dens[r]) / a.dt;     // :604, :613
             }
-            if (DEPOSIT) {
+            if (DEPOSIT && !LAG) {
                 lo[r] = rr[r] - .5 * drr[r];                                        // :655
                 up[r] = rr[r] + .5 * drr[r];
 #if defined(MSGW_ABLATE) && MSGW_ABLATE == 3
@@ -630,6 +634,16 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
                     ndens[r] = (maxd < d_in * pvf[r]) ? maxd : d_in;                // :604-608
                 }
             }
+            if (DEPOSIT && LAG) {                             // deposit of the NEW state (next stage's :654-658)
+                const double dn = (SAT || (DIRECT && STAGE == 2)) ? ndens[r] : dens[r];
+                lo[r] = nrr[r] - .5 * drr[r];
+                up[r] = nrr[r] + .5 * drr[r];
+                deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, a.inv_dzs, a.mk_ok, nc - 2, nlo[r], nup[r]);
+                double kh2n, m2n, vk2n, omn, cgn;
+                dispersion(kk[r], ll[r], nmm[r], f2, a.bvf2, kh2n, m2n, vk2n, omn, cgn);
+                pay[0][r] = cgn * kk[r] * dn;
+                pay[1][r] = cgn * ll[r] * dn;
+            }
         }
 
 #ifdef MSGW_STAMP
@@ -659,6 +673,48 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
         if (more) load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, base + TILE, tid, end);
     }
     if (DEPOSIT) flush_acc<2, NH>(s_rows + wave * 2 * ncp, ncp, lane, acc);
+}
+
+// Deposit-only pass over this workgroup's rays (no stores): wave_projection(var=0) of the CURRENT
+// state into the per-wave LDS rows.  Seeds the lagged-deposit pipeline of the persistent kernel.
+template <bool FVEC, int NH>
+__device__ __forceinline__ void deposit_pass(const StageArgs a, const StageLds L, long long start, long long end,
+                                             int tid, int wave, int lane)
+{
+    const int nc = a.ng - 1, ncp = a.ng - 2;
+    int wmin = INT_MAX, wmax = INT_MIN;
+    double acc[2][NH > 0 ? NH : 1];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int h = 0; h < (NH > 0 ? NH : 1); ++h) acc[p][h] = 0.0;
+    for (int t = 0; t < a.tiles_per_block; ++t) {
+        const long long base = start + (long long)t * TILE;
+        if (base >= end) break;
+        const long long e0 = base + 2 * tid;
+        const unsigned int off = (unsigned int)(e0 * 8);
+        const bool valid[2] = {e0 < end, e0 + 1 < end};
+        double rr[2], mm[2], kk[2], ll[2], dens[2], drr[2], vol[2], ff[2];
+        load2(a.r.rr, off, rr); load2(a.r.mm, off, mm); load2(a.r.kk, off, kk); load2(a.r.ll, off, ll);
+        load2(a.r.dens, off, dens); load2(a.r.drr, off, drr); load2(a.r.vol, off, vol);
+        if (FVEC) load2(a.r.fray, off, ff);
+        double lo[2], up[2], pay[2][2];
+        int nlo[2], nup[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double f = FVEC ? ff[r] : a.f_uni;
+            double kh2, m2, vk2, om, cgr;
+            dispersion(kk[r], ll[r], mm[r], f * f, a.bvf2, kh2, m2, vk2, om, cgr);
+            lo[r] = rr[r] - .5 * drr[r];
+            up[r] = rr[r] + .5 * drr[r];
+            deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, a.inv_dzs, a.mk_ok, nc - 2, nlo[r], nup[r]);
+            pay[0][r] = cgr * kk[r] * dens[r];
+            pay[1][r] = cgr * ll[r] * dens[r];
+        }
+        deposit_tile<2, NH>(lo, up, nlo, nup, vol, pay, L.gs, a.dzs, a.inv_dzs, a.mk_ok,
+                            L.rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
+    }
+    flush_acc<2, NH>(L.rows + wave * 2 * ncp, ncp, lane, acc);
 }
 
 // (A register double-buffered "prefetch next tile" variant was measured and dropped: its ~50

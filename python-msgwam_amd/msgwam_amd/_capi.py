@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmsgwam_hip.so")
+LIB_PATH = os.environ.get("MSGW_LIBRARY", os.path.join(HERE, "libmsgwam_hip.so"))   # override: diagnostic builds
 ROT_EARTH = 7.2921e-5          # lib/libprop.py:4
 
 FIXED_BACKGROUND = 1

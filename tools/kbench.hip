@@ -111,10 +111,12 @@ int main(int argc, char **argv)
         std::vector<unsigned long long> hs((size_t)blocks * 8);
         CK(hipMemcpy(hs.data(), dst, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull; for (int bI = 0; bI < blocks; ++bI) t0 = std::min(t0, hs[bI * 8]);
+#ifdef MSGW_DBG_LEVELS
         unsigned long long hl = 0, ht = 0, hw = 0;
         CK(hipMemcpyFromSymbol(&hl, HIP_SYMBOL(g_dbg_levels), 8)); CK(hipMemcpyFromSymbol(&ht, HIP_SYMBOL(g_dbg_tiles), 8));
         CK(hipMemcpyFromSymbol(&hw, HIP_SYMBOL(g_dbg_wide), 8));
         printf("  deposit: %llu wave-tiles, %llu level iterations (%.2f per wave-tile), %llu wide (atomic path)\n", ht, hl, (double)hl / ht, hw);
+#endif
         const char *nm[7] = {"entry", "col staged", "t0 physics", "t0 deposit", "t1 physics", "t1 deposit", "end"};
         for (int k = 0; k < 7; ++k) {
             std::vector<double> v; for (int bI = 0; bI < blocks; ++bI) if (hs[bI * 8 + k]) v.push_back((hs[bI * 8 + k] - t0) * 0.01);
