@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("MSGW_GRAPH_STEPS", 4)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-size-sweep", action="store_true", help="skip the extra 4x-rays measurement (N=1 only)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N=1 only: run the multi-GPU launch chain with a 1-rank RCCL communicator (diagnostic)")
     ap.add_argument("--kernel-events", choices=["separate", "same", "none"], default="separate",
                     help="where the per-launch HIP-event timing of the dominant kernel is taken")
     args = ap.parse_args()
@@ -129,6 +131,9 @@ def main():
     flags = _capi.FIXED_BACKGROUND if args.workload == "fixed" else 0
     same = args.kernel_events == "same"
     uid = None
+    if args.force_collective and world == 1:
+        os.environ["MSGW_FORCE_COLLECTIVE"] = "1"
+        uid = _capi.comm_unique_id()
     if world > 1:
         box = [_capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)

@@ -110,6 +110,9 @@ struct msgw_ctx {
     size_t grp_part_elems = 0;
     int grp_size = 1, ngroups = 1, row_stride = 0;
     bool groupred = false;           // set while enqueueing fused stages
+    bool lagchain = false;           // set while enqueueing the lagged launch chain (collectives overlap)
+    hipStream_t stream2 = nullptr;   // reduce + all-reduce of the next flux run here, beside the next K1
+    hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_flux[2] = {nullptr, nullptr};
     // persistent RK3 kernel (single rank, coupled)
     int persist = 1;                 // 0 disables (MSGW_PERSIST=0 or after a time-out)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
@@ -287,7 +290,7 @@ int ensure_groups(msgw_ctx *c)
         c->grp_part2_elems = need2;
     }
     if (!c->grp_rows) {
-        HIPCHK(c, hipMalloc(&c->grp_rows, sizeof(double) * (size_t)FUSE_ROWS * 2 * (c->ng - 2)));
+        HIPCHK(c, hipMalloc(&c->grp_rows, sizeof(double) * (size_t)2 * FUSE_ROWS * 2 * (c->ng - 2)));   // x2: flux parity
         HIPCHK(c, hipMalloc(&c->grp_cnt, sizeof(unsigned int) * 64));
         HIPCHK(c, hipMalloc(&c->grp_rows2, sizeof(double) * (size_t)2 * PERSIST_GROUPS * 2 * (c->ng - 2)));
         HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * 256));
@@ -344,6 +347,7 @@ StageArgs make_stage_args(msgw_ctx *c, double dt, unsigned flags)
     a.pg = c->pg; a.f0 = c->f0; a.dzg = c->dzg;
     a.grp_size = c->grp_size; a.row_stride = c->row_stride;
     a.grp_part = c->grp_part; a.grp_rows = c->grp_rows; a.grp_cnt = c->grp_cnt;
+    a.ngroups = c->ngroups; a.flux_out = c->flux;
     return a;
 }
 
@@ -402,6 +406,8 @@ int launch_stage_t(msgw_ctx *c, const StageArgs &a)
 {
     if (c->ng - 2 > 128)   // tall columns: per-level sums stay in LDS (NH = 0)
         return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 0>, stage_lds_bytes(c->ng), a);
+    if (c->lagchain && DEPOSIT && STAGE != 3)   // lagged chain: deposit of the produced state, group rows by parity
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, (DEPOSIT && STAGE != 3), (DEPOSIT && STAGE != 3)>, stage_lds_bytes(c->ng), a);
     if (c->groupred && DEPOSIT && STAGE != 3)   // fused chain: first-level flux reduction inside the kernel
         return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, (DEPOSIT && STAGE != 3)>, stage_lds_bytes(c->ng), a);
     return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2>, stage_lds_bytes(c->ng), a);
@@ -447,20 +453,21 @@ int launch_fixed(msgw_ctx *c, const StageArgs &a, int mode)
 }
 
 template <int STAGE, int MODE>
-int launch_column_t(msgw_ctx *c, const ColArgs &a)
+int launch_column_t(msgw_ctx *c, const ColArgs &a, hipStream_t stream = nullptr)
 {
     const size_t lds = col_lds_bytes(a.ng, a.nseg, a.npay * a.ncp, a.nblocks);
     auto k = k_column<STAGE, MODE>;
     if (int rc = ensure_lds(c, k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(1), dim3(COL_BLOCK), lds, c->stream, a);
+    hipLaunchKernelGGL(k, dim3(1), dim3(COL_BLOCK), lds, stream ? stream : c->stream, a);
     HIPCHK(c, hipGetLastError());
     return MSGW_OK;
 }
 
-int allreduce_flux(msgw_ctx *c)
+int allreduce_flux(msgw_ctx *c, double *buf = nullptr, hipStream_t stream = nullptr)
 {
     const size_t count = (size_t)2 * (c->ng - 2);
-    ncclResult_t r = g_rccl.AllReduce(c->flux, c->flux, count, ncclFloat64, ncclSum, c->comm, c->stream);
+    if (!buf) buf = c->flux;
+    ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, c->comm, stream ? stream : c->stream);
     if (r != 0)
         return fail(c, MSGW_ERR_RCCL, "ncclAllReduce failed: %s",
                     g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
@@ -564,12 +571,90 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     return MSGW_OK;
 }
 
+// Lagged launch chain for multi-GPU runs.  Pass q deposits the state it PRODUCES, i.e. publishes the
+// group rows of F_{q+1}; their reduction to one row and the RCCL all-reduce run on a second stream
+// WHILE the next ray-stage kernel executes (it needs F_q, reduced one pass earlier), so the
+// collective is off the critical path.  Per pass on stream A:  wait(F_{q-1} all-reduced) ->
+// k_ray_stage<LAG> -> record;  on stream B:  wait(row of F_{q+1}) ->
+// ncclAllReduce -> record (the ray-stage kernel itself reduces its rows to one row).  Group rows and
+// flux rows are double-buffered by flux parity.
+int enqueue_steps_lagged(msgw_ctx *c, double dt, unsigned flags, int count, bool time_kernels)
+{
+    const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
+    const int ncols = 2 * (c->ng - 2);
+    if (!c->stream2) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_flux[i], hipEventDisableTiming));
+        }
+    }
+    StageArgs sa = make_stage_args(c, dt, flags);
+    double *rows_par[2] = {c->grp_rows, c->grp_rows + (size_t)FUSE_ROWS * ncols};
+    double *flux_par[2] = {c->flux2, c->flux2 + ncols};
+    const ColIn in_set[2] = {ColIn{c->uu, c->vv, c->q_uu, c->q_vv}, ColIn{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
+    const ColOut out_set[2] = {ColOut{c->uu, c->vv, c->q_uu, c->q_vv}, ColOut{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
+    // reduce the group rows of flux f to one row and all-reduce it over the ranks, on stream B
+    auto reduce_on_b = [&](int f) -> int {
+        const int par = f & 1;
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_rows[par], 0));
+        if (c->comm)
+            if (int rc = allreduce_flux(c, flux_par[par], c->stream2)) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_flux[par], c->stream2));
+        return MSGW_OK;
+    };
+    c->lagchain = true;
+    struct Guard { msgw_ctx *c; ~Guard() { c->lagchain = false; c->time_next = false; } } guard{c};
+    // pre-pass: F_0
+    sa.grp_rows = rows_par[0];
+    sa.flux_out = flux_par[0];
+    {
+        const size_t lds = stage_lds_bytes(c->ng);
+        if (c->fvec) { if (int rc = launch_ray_kernel(c, k_deposit_only<true>, lds, sa)) return rc; }
+        else { if (int rc = launch_ray_kernel(c, k_deposit_only<false>, lds, sa)) return rc; }
+    }
+    HIPCHK(c, hipEventRecord(c->ev_rows[0], c->stream));
+    if (int rc = reduce_on_b(0)) return rc;
+    int cur = 0;
+    const int npass = 3 * count;
+    for (int q = 0; q < npass; ++q) {
+        const int s = q % 3;
+        sa.col_pending = q >= 1 ? 1 : 0;
+        sa.col_stage = (s + 2) % 3;                      // RK stage of the column update that yields column_q
+        sa.col_rows = flux_par[(q + 1) & 1];             // == parity of q-1: the all-reduced row of F_{q-1}
+        sa.cin = in_set[cur];
+        sa.cout = out_set[cur ^ 1];
+        sa.grp_rows = rows_par[(q + 1) & 1];             // this pass publishes F_{q+1} ...
+        sa.flux_out = flux_par[(q + 1) & 1];             // ... reduced in-kernel to one row
+        if (q >= 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_flux[(q - 1) & 1], 0));
+        c->time_next = time_kernels;
+        int rc = MSGW_OK;
+        if (s == 0) rc = launch_stage<0>(c, sa, mode);
+        else if (s == 1) rc = launch_stage<1>(c, sa, mode);
+        else rc = launch_stage<2>(c, sa, mode);
+        c->time_next = false;
+        if (rc) return rc;
+        if (q >= 1) cur ^= 1;
+        HIPCHK(c, hipEventRecord(c->ev_rows[(q + 1) & 1], c->stream));
+        if (q + 1 <= npass - 1)                          // F_{q+1} is consumed by pass q+2 <= npass (the final update)
+            if (int rc2 = reduce_on_b(q + 1)) return rc2;
+    }
+    // column_{npass} = update of column_{npass-1} with F_{npass-1}
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_flux[(npass - 1) & 1], 0));
+    ColArgs fin = make_col_args(c, dt, flags);
+    fin.flux = flux_par[(npass - 1) & 1];
+    fin.in = in_set[cur];
+    fin.out = out_set[0];
+    return launch_column_t<2, COL_UPDATE>(c, fin);
+}
+
 // Enqueue `count` RK3 steps (lib/libprop.py:693-698) on the context's stream.
 // Coupled mode chains the stages so that each stage's mean-flow update is applied in the
 // PROLOGUE of the next ray-stage kernel (all workgroups redo the tiny column update in LDS,
 // workgroup 0 publishes it to the other column set); only the very last update of the batch
 // runs as a standalone k_column, which always lands in the canonical set (c->uu, ...).
-//   per stage:  k_ray_stage -> k_flux_reduce1 [-> k_column<reduce> -> ncclAllReduce]
+//   per stage:  ONE launch of k_ray_stage (prologue: previous stage's column update from the one
+//   final flux row; tail: in-kernel reduction of its own rows to the next final row)
 int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_kernels)
 {
     if (count <= 0) return MSGW_OK;
@@ -601,16 +686,17 @@ int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_k
         }
         return MSGW_OK;
     }
+    if (c->nranks > 1 || (c->force_coll && c->comm))   // collectives: overlap them with the next pass
+        return enqueue_steps_lagged(c, dt, flags, count, time_kernels);
     int cur = 0;                       // set that holds the column BEFORE the pending update
     bool pending = false;
     int pend_stage = 0;
-    ColArgs rows{};                    // where the pending flux rows live
+    sa.col_rows = c->flux;             // every launch reduces its rows to this one row (in-kernel, three
+    sa.flux_out = c->flux;             // ticket levels); it is rewritten only after all prologues have read it
     for (int step = 0; step < count; ++step) {
         for (int s = 0; s < 3; ++s) {
             sa.col_pending = pending ? 1 : 0;
             sa.col_stage = pend_stage;
-            sa.col_rows = rows.partial;
-            sa.col_nrows = rows.nblocks;
             sa.cin = in_set[cur];
             sa.cout = out_set[cur ^ 1];
             int rc = MSGW_OK;
@@ -621,22 +707,15 @@ int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_k
             c->groupred = false;
             if (rc) return rc;
             if (pending) cur ^= 1;     // workgroup 0 has published the updated column there
-            rows = make_col_args(c, dt, flags);
-            rows.partial = c->grp_rows; rows.ranges = nullptr; rows.nblocks = c->ngroups;   // dense group rows
-            if (c->nranks > 1 || (c->force_coll && c->comm)) {   // local rows -> one flux row, summed over the ranks
-                if ((rc = launch_column_t<4, COL_REDUCE>(c, rows))) return rc;
-                if ((rc = allreduce_flux(c))) return rc;
-                rows.partial = c->flux; rows.ranges = nullptr; rows.nblocks = 1;
-            }
             pending = true;
             pend_stage = s;
         }
     }
     // the last update of the batch: standalone, from set `cur` into the canonical set
-    rows.in = in_set[cur];
-    rows.out = out_set[0];
-    rows.nseg = 1;                     // same (sequential) row order as the fused prologue: bitwise equal
-    return launch_column_t<2, COL_REDUCE | COL_UPDATE>(c, rows);
+    ColArgs fin = make_col_args(c, dt, flags);
+    fin.in = in_set[cur];
+    fin.out = out_set[0];
+    return launch_column_t<2, COL_UPDATE>(c, fin);
 }
 
 int ready(msgw_ctx *c)
@@ -694,7 +773,11 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     const size_t slot = (size_t)ngrid + 2;
     const int nslots = 24;
     CR(hipMalloc(&c->colbuf, slot * nslots * sizeof(double) * 2));
-    CR(hipMemset(c->colbuf, 0, slot * nslots * sizeof(double) * 2));
+    // on c->stream, NOT the null stream: c->stream is non-blocking, so a null-stream fill (asynchronous to the
+    // host for device memory) could land after msgw_set_column's uploads and wipe them
+    CR(hipMemsetAsync(c->colbuf, 0, slot * nslots * sizeof(double) * 2, c->stream));
+    for (double *p : c->ray_bufs) CR(hipMemsetAsync(p, 0, padded * sizeof(double), c->stream));
+    CR(hipStreamSynchronize(c->stream));
     double *b = c->colbuf;
     c->grid = b; b += slot; c->grids = b; b += slot; c->rhobar = b; b += slot;
     c->pg = b; b += 2 * slot; c->uu = b; b += slot; c->vv = b; b += slot;
@@ -731,6 +814,11 @@ int msgw_destroy(msgw_ctx *c)
     if (c->pdone) (void)hipFree(c->pdone);
     if (c->flux2) (void)hipFree(c->flux2);
     if (c->grp_part2) (void)hipFree(c->grp_part2);
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_rows[i]) (void)hipEventDestroy(c->ev_rows[i]);
+        if (c->ev_flux[i]) (void)hipEventDestroy(c->ev_flux[i]);
+    }
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

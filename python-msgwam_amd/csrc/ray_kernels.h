@@ -65,13 +65,14 @@ struct StageArgs {
     int row_stride;           // doubles per published row (multiple of 16: rows never share a 128-B line)
     double *grp_part;         // [blocks][row_stride]
     double *grp_rows;         // [ngroups][2*(ng-2)] dense group sums
-    unsigned int *grp_cnt;    // [ngroups] arrival tickets (zero between launches)
+    unsigned int *grp_cnt;    // [ngroups] arrival tickets, [63] completed groups (zero between launches)
+    int ngroups;              // number of groups
+    double *flux_out;         // [2*(ng-2)] final flux row of this launch (sum of the group sums)
     // Pending mean-flow update of the PREVIOUS RK stage, applied in this kernel's prologue by
     // every workgroup in LDS (workgroup 0 also publishes the new column to cout):
     int col_pending;      // 0: shear tables are read from c.dudz..; 1: apply the update below first
     int col_stage;        // RK stage (0, 1, 2) of that update
-    int col_nrows;        // dense flux rows to add up (fixed order) ...
-    const double *col_rows;   // ... [col_nrows][2*(ng-2)]
+    const double *col_rows;   // [2*(ng-2)] the final flux row of that stage
     const double *pg;     // pressure gradient [2][ng-1]
     double f0, dzg;       // config Coriolis parameter (:535), grid[1]-grid[0] (:349, :662)
     ColIn cin;            // column before the update (never written by this launch)
@@ -430,14 +431,46 @@ __device__ __forceinline__ void flush_rows_group(const double *rows, int ncp, in
         if (set == 1) { s_scr[2 * c2] = acc2.x; s_scr[2 * c2 + 1] = acc2.y; }
     }
     __syncthreads();
+    double *grow = a.grp_rows + (size_t)g * ncols;
     if (set == 0) {
-        double *dst = a.grp_rows + (size_t)g * ncols;
         const double x = acc2.x + s_scr[2 * c2], y = acc2.y + s_scr[2 * c2 + 1];
-        if (2 * c2 < ncols) dst[2 * c2] = x;
-        if (2 * c2 + 1 < ncols) dst[2 * c2 + 1] = y;
+        // group sums are re-read by another workgroup of this launch: write-through 8-byte stores
+        if (2 * c2 < ncols)
+            __hip_atomic_store(reinterpret_cast<u64 *>(grow + 2 * c2), (u64)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (2 * c2 + 1 < ncols)
+            __hip_atomic_store(reinterpret_cast<u64 *>(grow + 2 * c2 + 1), (u64)__double_as_longlong(y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 0)                                             // re-arm the ticket for the next launch
-        __hip_atomic_store(a.grp_cnt + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(a.grp_cnt + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm the ticket
+        const unsigned int t2 = __hip_atomic_fetch_add(a.grp_cnt + 63, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t2 == (unsigned int)a.ngroups - 1u) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+    // third level: the reducer of the launch's last group adds the group sums (group order) into the
+    // one row the next launch's prologue (or the all-reduce) reads
+    if (tid < ncols) {
+        double tot = 0.0;
+        for (int r = 0; r < a.ngroups; r += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                v[u] = __longlong_as_double((long long)__hip_atomic_load(
+                    reinterpret_cast<const u64 *>(a.grp_rows + (size_t)min(r + u, a.ngroups - 1) * ncols + tid),
+                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tot = tot + ((r + u < a.ngroups) ? v[u] : 0.0);
+        }
+        a.flux_out[tid] = tot;
+    }
+    if (tid == 0) __hip_atomic_store(a.grp_cnt + 63, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------ dispersion
@@ -721,7 +754,8 @@ __device__ __forceinline__ void deposit_pass(const StageArgs a, const StageLds L
 // extra VGPRs cost a wave of occupancy, capping it at 128 VGPRs spilled, and every spill reload
 // carries s_waitcnt vmcnt(0), which drains the prefetch.  The other resident workgroups cover
 // a workgroup's load latency instead.)
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH = 2, bool GROUPRED = false>
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH = 2, bool GROUPRED = false,
+          bool LAG = false>
 __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -743,24 +777,18 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
 
     MSGW_STAMP_AT(0);
     // Load order matters (vmcnt retires in order): first the handful of loads of the pending
-    // mean-flow update -- summed right away (about one L2 latency; holding 16 row registers
-    // across the ray-load issue costs a wave of occupancy) -- THEN the first tile's ray loads,
-    // so that the column math below runs while the ray data is in flight.  (Host guarantees
-    // 2*ncp <= BLOCK, nc <= BLOCK and col_nrows <= FUSE_ROWS whenever col_pending is set.)
+    // mean-flow update, THEN the first tile's ray loads, so that the column math below runs
+    // while the ray data is in flight.  (Host guarantees 2*ncp <= BLOCK and nc <= BLOCK
+    // whenever col_pending is set.)
     const bool fuse = DEPOSIT && a.col_pending;
     const int ncols = 2 * ncp;
     double c_tot = 0.0, c_u = 0, c_v = 0, c_qu = 0, c_qv = 0, c_rho = 1, c_pg0 = 0, c_pg1 = 0;
     if (fuse) {
         const int col = min(tid, ncols - 1), jc = min(tid, nc - 1);
-        double prow[FUSE_ROWS];
-#pragma unroll
-        for (int u = 0; u < FUSE_ROWS; ++u)
-            prow[u] = a.col_rows[(size_t)min(u, a.col_nrows - 1) * ncols + col];
+        c_tot = a.col_rows[col];                             // the final (all-reduced) flux row
         c_u = a.cin.uu[jc]; c_v = a.cin.vv[jc];
         c_qu = a.cin.q_uu[jc]; c_qv = a.cin.q_vv[jc];
         c_rho = a.c.rhobar[jc]; c_pg0 = a.pg[jc]; c_pg1 = a.pg[nc + jc];
-#pragma unroll
-        for (int u = 0; u < FUSE_ROWS; ++u) c_tot = c_tot + ((u < a.col_nrows) ? prow[u] : 0.0);   // row order
     }
     TileRegs cur;
     load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, start, tid, end);
@@ -811,12 +839,34 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
 
     int wmin = INT_MAX, wmax = INT_MIN;
     const StageLds L{s_sh, s_rho2, s_xg, s_gs, s_rows};
-    process_tiles<STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH>(a, L, cur, start, end, tid, wave, lane, wmin, wmax);
+    process_tiles<STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH, LAG>(a, L, cur, start, end, tid, wave, lane, wmin, wmax);
     if (DEPOSIT) {
         if (GROUPRED) flush_rows_group<2>(s_rows, ncp, s_rng, lds /* interp tables are dead by now */, tid, a);
         else flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
     }
     MSGW_STAMP_AT(6);
+}
+
+// Deposit-only launch that seeds the lagged launch chain: F_0 = wave_projection(state_0) into the
+// group rows (same LDS carve and group reduction as k_ray_stage).
+template <bool FVEC>
+__global__ void __launch_bounds__(BLOCK) k_deposit_only(const StageArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
+    double *s_xg = lds + 4 * ni + 2 * nc;
+    double *s_gs = s_xg + ni;
+    double *s_rows = s_gs + nc;
+    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * 2 * ncp);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long start = (long long)blockIdx.x * a.rays_per_block;
+    const long long end = min(a.n, start + a.rays_per_block);
+    for (int i = tid; i < nc; i += BLOCK) s_gs[i] = a.c.grids[i];
+    for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) s_rows[i] = 0.0;
+    __syncthreads();
+    const StageLds L{nullptr, nullptr, s_xg, s_gs, s_rows};
+    deposit_pass<FVEC, 2>(a, L, start, end, tid, wave, lane);
+    flush_rows_group<2>(s_rows, ncp, s_rng, lds, tid, a);
 }
 
 // ------------------------------------------------------------------ K1f: fixed background, whole RK3 step in registers

@@ -290,24 +290,45 @@ def test_tall_column_path_vs_c_oracle():
 
 
 def test_collective_chain_with_one_rank_communicator(monkeypatch):
-    """The multi-GPU chain (k_column<reduce> -> ncclAllReduce -> 1-row prologue) exercised with a
-    1-rank RCCL communicator: results must equal the plain single-GPU path bit for bit
-    (an all-reduce over one rank is the identity)."""
-    monkeypatch.setenv("MSGW_FORCE_COLLECTIVE", "1")
+    """The multi-GPU chain exercised with a 1-rank RCCL communicator (an all-reduce over one rank is
+    the identity): lagged launch chain = k_deposit_only, then per pass k_ray_stage<LAG> on stream A
+    while k_column<reduce> + ncclAllReduce of the next flux run on stream B.  It deposits exactly the
+    values the plain launch chain deposits (same state, same group order), so the results must be
+    BITWISE equal to the plain chain (MSGW_PERSIST=0, no communicator)."""
     s, st = _random_case(120_000, 41, False, "uniform", True)
+    monkeypatch.setenv("MSGW_PERSIST", "0")
     ref = make_prop(s, st)
+    ref.step(60.0, 2)
     ref.step(60.0, 5)
     want = gpu_state(ref, st)
     ref.close()
+    monkeypatch.setenv("MSGW_FORCE_COLLECTIVE", "1")
     for graph_steps in (0, 2):
         p = make_prop(s, st)
         p.comm_init(_capi.comm_unique_id(), 0, 1)
         p.set_tuning(4, graph_steps)
+        p.step(60.0, 2)
         p.step(60.0, 5)
         got = gpu_state(p, st)
         assert p.counters()["nranks"] == 1
         p.close()
-        check_state(got, want, 1e-12, 1e-12, f"collective graph={graph_steps}")
+        for k, a, b in zip(STATE_KEYS, got, want):
+            assert np.array_equal(a, b, equal_nan=True), f"lagged collective chain differs from the plain chain in {k}"
+    # and with online saturation + per-ray latitude (other kernel variants of the chain)
+    s2, st2 = _random_case(40_001, 42, True, "vector", True)
+    monkeypatch.delenv("MSGW_FORCE_COLLECTIVE")
+    ref = make_prop(s2, st2)
+    ref.step(60.0, 3)
+    want = gpu_state(ref, st2)
+    ref.close()
+    monkeypatch.setenv("MSGW_FORCE_COLLECTIVE", "1")
+    p = make_prop(s2, st2)
+    p.comm_init(_capi.comm_unique_id(), 0, 1)
+    p.step(60.0, 3)
+    got = gpu_state(p, st2)
+    p.close()
+    for k, a, b in zip(STATE_KEYS, got, want):
+        assert np.array_equal(a, b, equal_nan=True), f"lagged chain (saturation) differs in {k}"
 
 
 def test_persistent_kernel_equals_per_stage_kernels(monkeypatch):
