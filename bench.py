@@ -100,7 +100,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-size-sweep", action="store_true", help="skip the extra 4x-rays measurement (N=1 only)")
     ap.add_argument("--force-collective", action="store_true",
-                    help="N=1 only: run the multi-GPU launch chain with a 1-rank RCCL communicator (diagnostic)")
+                    help="N=1 only: run the multi-GPU path with a 1-rank communicator (diagnostic; "
+                         "MSGW_EXCHANGE=0 selects the RCCL launch chain instead of the in-kernel exchange)")
     ap.add_argument("--kernel-events", choices=["separate", "same", "none"], default="separate",
                     help="where the per-launch HIP-event timing of the dominant kernel is taken")
     args = ap.parse_args()
@@ -234,8 +235,11 @@ def main():
                                     if args.workload == "coupled" else
                                     "config2-style: fixed background, pure propagation, fp64"),
                        "rays_total": n_total, "rays_per_gpu": args.rays_per_gpu, "ngrid": args.ngrid,
-                       "dt": DT, "parallelism": f"rays sharded x{world}, flux all-reduce per RK stage"
-                       if world > 1 else "single GPU",
+                       "dt": DT, "parallelism": (f"rays sharded x{world}, column replicated; flux summed over the ranks " +
+                                                 ("inside the persistent kernel (node-shared segment, rank order)"
+                                                  if c1.get("exchange") and persist_steps else
+                                                  "by ncclAllReduce once per RK stage (lagged launch chain)"))
+                       if (world > 1 or args.force_collective) else "single GPU",
                        "graph_steps": c1["graph_steps"], "persist_steps": persist_steps, "blocks": c1["blocks"]},
             "whole_job_hbm_frac": value * bps / 1e9 / (HBM_PEAK_GBS * world),
             "state_finite": finite,

@@ -59,7 +59,7 @@ typedef struct {
     int32_t graph_steps;         /* RK3 steps per captured graph (0 = eager)                    */
     int32_t nranks;              /* communicator size (1 = no collective)                       */
     int32_t persist_steps;       /* RK3 steps done by the last persistent launch (0 = per-stage kernels) */
-    int32_t reserved_;
+    int32_t exchange;            /* 1: multi-rank steps use the in-kernel node-level flux exchange */
 } msgw_counters_t;
 
 /* ABI version of the loaded library (== MSGW_ABI_VERSION). */

@@ -5,6 +5,12 @@
 #include "msgwam_hip.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
@@ -30,7 +36,7 @@ std::string g_create_error;
 typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 typedef int ncclResult_t;
-enum { ncclFloat64 = 8, ncclSum = 0 };   // ncclDataType_t / ncclRedOp_t values in rccl.h
+enum { ncclInt32 = 2, ncclFloat64 = 8, ncclSum = 0, ncclMin = 3 };   // ncclDataType_t / ncclRedOp_t values in rccl.h
 struct RcclApi {
     void *handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -62,6 +68,19 @@ struct RcclApi {
 } g_rccl;
 
 }   // namespace
+
+// Head of the node-level exchange segment (POSIX shared memory, one per communicator).  The host
+// side uses the counters to agree on the outcome of the set-up; the GPUs use flags[] and rows[].
+struct XchHeader {
+    unsigned int magic;           // written last by rank 0
+    unsigned int nranks;
+    unsigned int arrived[4];      // host barriers of the set-up
+    unsigned int okay[4];         // ranks that reached the barrier without an error
+};
+constexpr unsigned int XCH_MAGIC = 0x4d534758u;                 // "MSGX"
+constexpr size_t XCH_FLAGS_OFF = 4096;                          // [nranks][8] u64, one 64-byte line per rank
+constexpr unsigned long long XCH_TIMEOUT_TICKS = 2000000000ull; // 20 s of wall clock (100 MHz): ranks start apart
+constexpr int XCH_TEST_ROUNDS = 6;
 
 struct msgw_ctx {
     int device = 0;
@@ -116,7 +135,7 @@ struct msgw_ctx {
     // persistent RK3 kernel (single rank, coupled)
     int persist = 1;                 // 0 disables (MSGW_PERSIST=0 or after a time-out)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
-    unsigned int *pdone = nullptr;   // [0] ready, [1] status, [2..3] done2, [64..191] group tickets
+    unsigned int *pdone = nullptr;   // [0] ready, [1] status, [2..3] done2, [4] local_ready, [64..191] group tickets
     double *flux2 = nullptr;         // [2][ncols] final flux rows of the persistent kernel
     unsigned long long *pstamps = nullptr;   // diagnostic builds only
     double *grp_part2 = nullptr;     // [2][blocks][row_stride]
@@ -135,6 +154,16 @@ struct msgw_ctx {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     bool force_coll = false;
+    // node-level in-kernel exchange of the persistent kernel: POSIX shared memory, registered with HIP
+    struct XchHeader *xch_hdr = nullptr;      // host mapping of the whole segment
+    size_t xch_bytes = 0;
+    bool xch_registered = false;
+    double *xch_rows = nullptr;               // device view of the rank rows
+    unsigned long long *xch_flags = nullptr;  // device view of the sequence numbers
+    int xch_stride = 0;
+    unsigned long long xch_seq = 0;           // sequence number of the newest flux exchanged
+    bool xch_ok = false;                      // agreed by all ranks after the self-test
+    int *xch_scratch = nullptr;               // device int: self-test result / agreement buffer
 
     // counters / kernel timing
     msgw_counters_t cnt{};
@@ -144,6 +173,8 @@ struct msgw_ctx {
 };
 
 namespace {
+
+void xch_teardown(msgw_ctx *c);
 
 int fail(msgw_ctx *c, int code, const char *fmt, ...)
 {
@@ -294,7 +325,7 @@ int ensure_groups(msgw_ctx *c)
         HIPCHK(c, hipMalloc(&c->grp_cnt, sizeof(unsigned int) * 64));
         HIPCHK(c, hipMalloc(&c->grp_rows2, sizeof(double) * (size_t)2 * PERSIST_GROUPS * 2 * (c->ng - 2)));
         HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * 256));
-        HIPCHK(c, hipMalloc(&c->flux2, sizeof(double) * (size_t)2 * 2 * (c->ng - 2)));
+        HIPCHK(c, hipMalloc(&c->flux2, sizeof(double) * (size_t)4 * 2 * (c->ng - 2)));   // [2] final + [2] this rank's
     }
     HIPCHK(c, hipMemsetAsync(c->grp_cnt, 0, sizeof(unsigned int) * 64, c->stream));
     return MSGW_OK;
@@ -467,6 +498,9 @@ int allreduce_flux(msgw_ctx *c, double *buf = nullptr, hipStream_t stream = null
 {
     const size_t count = (size_t)2 * (c->ng - 2);
     if (!buf) buf = c->flux;
+    if (!c->comm)
+        return fail(c, MSGW_ERR_RCCL, "this step needs the RCCL all-reduce chain, but the communicator was set up "
+                    "without RCCL (MSGW_EXCHANGE_ONLY=1)");
     ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, c->comm, stream ? stream : c->stream);
     if (r != 0)
         return fail(c, MSGW_ERR_RCCL, "ncclAllReduce failed: %s",
@@ -501,7 +535,8 @@ int launch_persist_t(msgw_ctx *c, PersistArgs &pa, bool *resident)
     if (int rc = ensure_lds(c, k, lds)) return rc;
     int per_cu = 0;
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, BLOCK, lds));
-    *resident = (long long)per_cu * c->ncu >= c->blocks && c->blocks <= 2048;   // every workgroup co-resident
+    const int grid = c->blocks + (pa.xch ? 1 : 0);             // + the exchange workgroup
+    *resident = (long long)per_cu * c->ncu >= grid && grid <= 2048;             // every workgroup co-resident
     if (!*resident) return MSGW_OK;
     pa.s.grp_size = (c->blocks + PERSIST_GROUPS - 1) / PERSIST_GROUPS;
     pa.ngroups = (c->blocks + pa.s.grp_size - 1) / pa.s.grp_size;
@@ -510,7 +545,7 @@ int launch_persist_t(msgw_ctx *c, PersistArgs &pa, bool *resident)
         hipEvent_t *ev = timing_events(c);
         if (ev) { e0 = ev[0]; e1 = ev[1]; }
     }
-    hipExtLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, e0, e1, 0, pa);
+    hipExtLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, c->stream, e0, e1, 0, pa);
     HIPCHK(c, hipGetLastError());
     return MSGW_OK;
 }
@@ -521,7 +556,8 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
 {
     *used = false;
     const bool can_fuse = (2 * (c->ng - 2) <= BLOCK) && (c->ng - 1 <= BLOCK);
-    if (!c->persist || !can_fuse || c->nranks > 1 || (c->force_coll && c->comm) || (flags & MSGW_FIXED_BACKGROUND) || count <= 0)
+    const bool multi = c->nranks > 1 || c->force_coll;
+    if (!c->persist || !can_fuse || (multi && !c->xch_ok) || (flags & MSGW_FIXED_BACKGROUND) || count <= 0)
         return MSGW_OK;
     const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
     PersistArgs pa{};
@@ -533,6 +569,7 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.ready = c->pdone;
     pa.status = reinterpret_cast<int *>(c->pdone + 1);
     pa.done2 = c->pdone + 2;
+    pa.nworkers = c->blocks;
     pa.grp_cnt2 = c->pdone + 64;
 #ifdef MSGW_STAMP
     if (!c->pstamps) HIPCHK(c, hipMalloc(&c->pstamps, sizeof(unsigned long long) * 4096 * PSTAMP_PASSES * 4));
@@ -540,6 +577,16 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.pstamps = c->pstamps;
 #endif
     pa.timeout_ticks = 20000000ull;                            // 0.2 s of wall clock per wait
+    XchArgs x{};                                               // lives until the stream is synchronised below
+    if (multi) {                                               // the other ranks' launches may start much later
+        x.nranks = c->nranks; x.rank = c->rank; x.stride = c->xch_stride;
+        x.rows = c->xch_rows; x.flags = c->xch_flags; x.seq = c->xch_seq;
+        x.timeout_ticks = XCH_TIMEOUT_TICKS;
+        XchArgs *dx = reinterpret_cast<XchArgs *>(c->xch_scratch + 16);
+        HIPCHK(c, hipMemcpyAsync(dx, &x, sizeof x, hipMemcpyHostToDevice, c->stream));
+        pa.xch = dx;
+        pa.timeout_ticks = XCH_TIMEOUT_TICKS + 100000000ull;
+    }
     pa.cin = ColIn{c->uu, c->vv, c->q_uu, c->q_vv};
     pa.cout = ColOut{c->uu, c->vv, c->q_uu, c->q_vv};
     pa.dudz = c->dudz; pa.dvdz = c->dvdz; pa.slu = c->slu; pa.slv = c->slv;
@@ -556,6 +603,7 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     if (!resident) return MSGW_OK;                             // grid larger than residency: per-stage path
     *used = true;
     c->cnt.persist_steps = count;
+    if (multi) c->xch_seq += 3ull * (unsigned long long)count + 1ull;   // fluxes 0 .. 3*count were exchanged
     // the waits are bounded; a raised status means a workgroup was not resident (or the GPU is
     // shared): report it loudly, never spin forever
     int status = 0;
@@ -564,6 +612,9 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     if (status != 0) {
         c->persist = 0;
         c->have_rays = false;                                  // the step was abandoned half-way
+        if (multi)
+            return fail(c, MSGW_ERR_HIP, "persistent RK3 kernel timed out in the node-level flux exchange (a rank "
+                        "died, or the ranks did not call msgw_step alike); state is invalid");
         return fail(c, MSGW_ERR_HIP, "persistent RK3 kernel timed out waiting for other workgroups "
                     "(not all of them resident?); state is invalid, upload the rays again "
                     "(the per-stage kernels will be used from now on)");
@@ -801,6 +852,7 @@ int msgw_destroy(msgw_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    xch_teardown(c);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     for (double *p : c->ray_bufs) (void)hipFree(p);
     if (c->colbuf) (void)hipFree(c->colbuf);
@@ -1188,24 +1240,177 @@ int msgw_comm_unique_id(void *id128)
     return MSGW_OK;
 }
 
+namespace {
+
+double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+void xch_teardown(msgw_ctx *c)
+{
+    if (c->xch_registered) { (void)hipHostUnregister(c->xch_hdr); c->xch_registered = false; }
+    if (c->xch_hdr) { munmap(c->xch_hdr, c->xch_bytes); c->xch_hdr = nullptr; }
+    if (c->xch_scratch) { (void)hipFree(c->xch_scratch); c->xch_scratch = nullptr; }
+    c->xch_rows = nullptr; c->xch_flags = nullptr; c->xch_ok = false; c->xch_bytes = 0;
+}
+
+// Host barrier `k` of the set-up: every rank reports `ok`; returns true when all ranks arrived in
+// time and all of them reported ok.
+bool xch_barrier(msgw_ctx *c, int k, bool ok, double timeout_s)
+{
+    XchHeader *h = c->xch_hdr;
+    if (ok) __atomic_fetch_add(&h->okay[k], 1u, __ATOMIC_ACQ_REL);
+    __atomic_fetch_add(&h->arrived[k], 1u, __ATOMIC_ACQ_REL);
+    const double t0 = now_s();
+    while (__atomic_load_n(&h->arrived[k], __ATOMIC_ACQUIRE) < (unsigned int)c->nranks) {
+        if (now_s() - t0 > timeout_s) return false;
+        usleep(200);
+    }
+    return __atomic_load_n(&h->okay[k], __ATOMIC_ACQUIRE) == (unsigned int)c->nranks;
+}
+
+// When there is an RCCL communicator the outcome is also agreed through it (covers ranks on
+// other nodes, which can never join this node's segment).
+bool xch_agree_rccl(msgw_ctx *c, bool ok)
+{
+    if (!c->comm) return ok;
+    int v = ok ? 1 : 0;
+    if (hipMemcpyAsync(c->xch_scratch + 1, &v, sizeof v, hipMemcpyHostToDevice, c->stream) != hipSuccess) return false;
+    if (g_rccl.AllReduce(c->xch_scratch + 1, c->xch_scratch + 1, 1, ncclInt32, ncclMin, c->comm, c->stream) != 0) return false;
+    if (hipMemcpyAsync(&v, c->xch_scratch + 1, sizeof v, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+    return v == 1;
+}
+
+// Create/join the communicator's segment, map it into the GPU, run the self-test, agree.  Never
+// fatal: on any failure xch_ok stays false and multi-rank steps use the all-reduce launch chain.
+void xch_setup(msgw_ctx *c, const void *id128, std::string &why)
+{
+    xch_teardown(c);
+    c->xch_seq = 0;
+    if (hipMalloc(&c->xch_scratch, 256) != hipSuccess) { (void)hipGetLastError(); why = "hipMalloc"; return; }
+    // the name is derived from the communicator's unique id (FNV-1a), identical on all ranks
+    unsigned long long hsh = 1469598103934665603ull;
+    for (int i = 0; i < 128; ++i) hsh = (hsh ^ ((const unsigned char *)id128)[i]) * 1099511628211ull;
+    char name[64];
+    snprintf(name, sizeof name, "/msgw-%016llx", hsh);
+    const int ncols = 2 * (c->ng - 2);
+    const int stride = ((ncols > 64 ? ncols : 64) + 7) / 8 * 8;
+    const size_t flags_bytes = ((size_t)c->nranks * 64 + 4095) / 4096 * 4096;
+    const size_t rows_off = XCH_FLAGS_OFF + flags_bytes;
+    const size_t bytes = (rows_off + sizeof(double) * 2 * (size_t)c->nranks * stride + 4095) / 4096 * 4096;
+    const double join_timeout = 60.0;
+    int fd = -1;
+    bool ok = true;
+    if (c->rank == 0) {
+        shm_unlink(name);                                      // a stale segment of a crashed run
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) { ok = false; why = "shm_open/ftruncate"; }
+    } else {
+        const double t0 = now_s();
+        for (;;) {
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size == bytes) break;
+            if (fd >= 0) { close(fd); fd = -1; }
+            if (now_s() - t0 > join_timeout) { ok = false; why = "segment of rank 0 not found (another node?)"; break; }
+            usleep(1000);
+        }
+    }
+    void *m = MAP_FAILED;
+    if (ok) m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (fd >= 0) close(fd);
+    if (ok && m == MAP_FAILED) { ok = false; why = "mmap"; }
+    if (!ok) {
+        if (c->rank == 0) shm_unlink(name);
+        (void)xch_agree_rccl(c, false);
+        return;
+    }
+    c->xch_hdr = static_cast<XchHeader *>(m);
+    c->xch_bytes = bytes;
+    XchHeader *h = c->xch_hdr;
+    if (c->rank == 0) {                                        // ftruncate zero-filled the segment
+        h->nranks = (unsigned int)c->nranks;
+        __atomic_store_n(&h->magic, XCH_MAGIC, __ATOMIC_RELEASE);
+    } else {
+        const double t0 = now_s();
+        while (__atomic_load_n(&h->magic, __ATOMIC_ACQUIRE) != XCH_MAGIC && now_s() - t0 < join_timeout) usleep(200);
+        if (h->magic != XCH_MAGIC || h->nranks != (unsigned int)c->nranks) { ok = false; why = "segment header mismatch"; }
+    }
+    // map the segment into this rank's GPU (fine-grained: host memory is never cached by the GPU)
+    void *dev = nullptr;
+    if (ok) {
+        if (hipHostRegister(m, bytes, hipHostRegisterMapped) == hipSuccess) c->xch_registered = true;
+        else { (void)hipGetLastError(); ok = false; why = "hipHostRegister"; }
+    }
+    if (ok && hipHostGetDevicePointer(&dev, m, 0) != hipSuccess) { (void)hipGetLastError(); ok = false; why = "hipHostGetDevicePointer"; }
+    ok = xch_barrier(c, 0, ok, join_timeout) && ok;            // everybody has opened the segment ...
+    if (c->rank == 0) shm_unlink(name);                        // ... so its name can go
+    if (ok) {
+        c->xch_flags = reinterpret_cast<unsigned long long *>(static_cast<char *>(dev) + XCH_FLAGS_OFF);
+        c->xch_rows = reinterpret_cast<double *>(static_cast<char *>(dev) + rows_off);
+        c->xch_stride = stride;
+        XchTestArgs t{};
+        t.nranks = c->nranks; t.rank = c->rank; t.stride = stride; t.rounds = XCH_TEST_ROUNDS;
+        t.rows = c->xch_rows; t.flags = c->xch_flags; t.timeout_ticks = XCH_TIMEOUT_TICKS; t.result = c->xch_scratch;
+        int res = 0;
+        ok = hipMemsetAsync(c->xch_scratch, 0, 64, c->stream) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(k_xch_selftest, dim3(1), dim3(BLOCK), 0, c->stream, t);
+            ok = hipGetLastError() == hipSuccess &&
+                 hipMemcpyAsync(&res, c->xch_scratch, sizeof res, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                 hipStreamSynchronize(c->stream) == hipSuccess && res == 1;
+        }
+        if (!ok) why = "self-test (rows of the other ranks not seen)";
+    }
+    ok = xch_barrier(c, 1, ok, join_timeout) && ok;
+    ok = xch_agree_rccl(c, ok);
+    if (!ok && why.empty()) why = "another rank failed";
+    c->xch_ok = ok;
+    c->xch_seq = XCH_TEST_ROUNDS;                              // the self-test used sequence numbers 1..rounds
+    if (!ok) xch_teardown(c);
+}
+
+}   // namespace
+
 int msgw_comm_init(msgw_ctx *c, const void *id128, int rank, int nranks)
 {
     if (!c || !id128) return fail(c, MSGW_ERR_ARG, "NULL argument");
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MSGW_ERR_ARG, "bad rank %d / %d", rank, nranks);
-    if (!g_rccl.load()) return fail(c, MSGW_ERR_RCCL, "%s", g_rccl.load_error.c_str());
+    // MSGW_EXCHANGE_ONLY=1: no RCCL communicator at all (single node, every coupled step must then be
+    // able to take the persistent kernel); also the way two ranks can share ONE GPU in tests, which
+    // RCCL refuses.  MSGW_EXCHANGE=0: never use the in-kernel exchange (always the all-reduce chain).
+    const char *eo = std::getenv("MSGW_EXCHANGE_ONLY");
+    const bool exchange_only = eo && std::atoi(eo) != 0;
+    const char *ex = std::getenv("MSGW_EXCHANGE");
+    const bool want_exchange = exchange_only || !(ex && std::atoi(ex) == 0);
     HIPCHK(c, hipSetDevice(c->device));
-    ncclUniqueId id;
-    std::memcpy(&id, id128, sizeof id);
     if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
-    ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
-    if (r != 0)
-        return fail(c, MSGW_ERR_RCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    if (!exchange_only) {
+        if (!g_rccl.load()) return fail(c, MSGW_ERR_RCCL, "%s", g_rccl.load_error.c_str());
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof id);
+        ncclResult_t r = g_rccl.CommInitRank(&c->comm, nranks, id, rank);
+        if (r != 0)
+            return fail(c, MSGW_ERR_RCCL, "ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
     c->rank = rank;
     c->nranks = nranks;
     c->cnt.nranks = nranks;
     // MSGW_FORCE_COLLECTIVE=1: run the all-reduce chain even for a 1-rank communicator, so that the
     // multi-GPU code path (reduce -> ncclAllReduce -> 1-row prologue) can be tested on a 1-GPU box
     if (const char *e = std::getenv("MSGW_FORCE_COLLECTIVE")) c->force_coll = std::atoi(e) != 0;
+    std::string why;
+    if (want_exchange && (nranks > 1 || c->force_coll)) xch_setup(c, id128, why);
+    else xch_teardown(c);
+    c->cnt.exchange = c->xch_ok ? 1 : 0;
+    if (exchange_only && !c->xch_ok && nranks > 1)
+        return fail(c, MSGW_ERR_RCCL, "MSGW_EXCHANGE_ONLY=1 but the node-level exchange could not be set up: %s", why.c_str());
+    if (!c->xch_ok && !why.empty() && std::getenv("MSGW_VERBOSE"))
+        fprintf(stderr, "msgwam_hip: rank %d: in-kernel exchange unavailable (%s); using the RCCL launch chain\n", rank, why.c_str());
     drop_graph(c);
     return MSGW_OK;
 }

@@ -25,12 +25,38 @@
 //
 // Every wait is bounded (wall clock); on time-out a status word is raised and all workgroups
 // leave.  The host sizes the grid from the occupancy query (all workgroups must be resident).
+//
+// Several GPUs (one process each, rays sharded, column replicated).  The workgroup that forms a
+// rank's final row of a flux also does the node-level exchange, inside the kernel: it stores the
+// row into a host-resident segment that every rank of the node has mapped (fine-grained memory,
+// reached over PCIe; system-scope stores, release, then the rank's sequence number), waits
+// (bounded) until every rank's sequence number has reached this flux, and adds the rank rows in
+// rank order -- the same arithmetic on every rank, so the replicated columns stay bitwise
+// identical.  The exchange has the same one-pass slack as the local reduction (lagged deposit),
+// i.e. a few microseconds of PCIe latency are hidden behind the next pass.  No launch, no
+// collective kernel, no cross-stream events per RK stage.  The exchange is done by ONE extra
+// workgroup without rays (the last of the grid): if the reducing workgroup did it, the workgroup
+// that is the slowest by construction would start its next pass ~8 us later still, and that showed
+// up as +3.6 us per pass; with the exchange workgroup a multi-rank pass costs what a single-GPU
+// pass costs.
 #pragma once
 #include "ray_kernels.h"
 
 namespace msgw {
 
 constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
+
+// Node-level exchange: fine-grained host memory mapped by all ranks.  Read by the exchange
+// workgroup only, so it lives in device memory instead of widening every workgroup's arguments.
+struct XchArgs {
+    int nranks, rank;
+    int stride;                   // doubles per rank row (a multiple of 8)
+    int pad_;
+    double *rows;                 // [2][nranks][stride] rank rows, by parity of the sequence number
+    unsigned long long *flags;    // [nranks][8]  sequence number of the newest row a rank has published
+    unsigned long long seq;       // sequence number of this launch's flux 0, minus 1
+    unsigned long long timeout_ticks;
+};
 
 struct PersistArgs {
     StageArgs s;                  // rays, constants, static column tables; grp_size/row_stride
@@ -42,8 +68,12 @@ struct PersistArgs {
     unsigned int *grp_cnt2;       // [2][64] arrival tickets of the groups   (zero at launch)
     unsigned int *done2;          // [2] completed groups of a flux          (zero at launch)
     unsigned int *ready;          // fluxes whose final row is published     (zero at launch)
+                                  // several ranks: ready[4] counts the fluxes whose LOCAL row is complete and
+                                  // flux2 + 2 * 2*(ng-2) holds [2][2*(ng-2)] this rank's rows, by flux parity
+    int nworkers;                 // workgroups that own rays (the grid has one more when xch is set)
     int *status;                  // 0 ok, 1 a wait timed out
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
+    const struct XchArgs *xch;    // several ranks: the node-level exchange (device memory); else nullptr
     ColIn cin;                    // canonical column at entry
     ColOut cout;                  // canonical column at exit (workgroup 0)
     double *dudz, *dvdz, *slu, *slv;    // derived tables at exit (workgroup 0)
@@ -72,14 +102,76 @@ __device__ __forceinline__ void st_agent(double *p, double v)
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ double ld_sys(const double *p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64_t *>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ void st_sys(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<u64_t *>(p), (u64_t)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Wave 0: every lane r < nranks polls rank r's sequence number until it reaches `seq` (bounded).
+__device__ __forceinline__ bool xch_wait_all(const u64_t *flags, int nranks, u64_t seq, int *status,
+                                             u64_t timeout_ticks, int lane)
+{
+    bool ok = true;
+    if (lane < nranks) {
+        const u64_t *fl = flags + 8 * lane;
+        if (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            const u64_t t0 = wall_clock64();
+            while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+                __builtin_amdgcn_s_sleep(4);
+                if ((status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ||
+                    wall_clock64() - t0 > timeout_ticks) {
+                    ok = false;
+                    break;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // compiler-only: rows are read with system-scope loads
+    return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+}
+
+// Node-level sum of one row per rank (see the header comment).  `mine` is this rank's value of
+// column `tid`; returns false after a time-out.  s_flag: an LDS word not used by other hand-offs.
+__device__ __forceinline__ bool xch_allsum(int nranks, int rank, int stride, double *rows, u64_t *flags, u64_t seq,
+                                           int *status, u64_t timeout_ticks, int ncols, int tid, int *s_flag,
+                                           double mine, double &tot)
+{
+    double *slot = rows + (size_t)(seq & 1ull) * nranks * stride;
+    if (tid < ncols) st_sys(slot + (size_t)rank * stride + tid, mine);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // system scope: every storing wave's row is out
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flags + 8 * rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < 64) {
+        const bool ok = xch_wait_all(flags, nranks, seq, status, timeout_ticks, tid);
+        if (tid == 0) {
+            if (!ok && status) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_flag = ok ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (!*s_flag) return false;
+    tot = 0.0;
+    if (tid < ncols)
+        for (int r = 0; r < nranks; ++r) tot = tot + ld_sys(slot + (size_t)r * stride + tid);   // rank order
+    return true;
+}
+
 // Wait until *ready >= target stages (one lane polls, bounded), then release the workgroup.
-__device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int target, int *s_flag, int tid)
+__device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int target, int *s_flag, int tid,
+                                             const unsigned int *counter = nullptr)
 {
     if (tid == 0) {
         int ok = 1;
-        if (__hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (!counter) counter = p.ready;
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(8);
                 if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                     wall_clock64() - t0 > p.timeout_ticks) {
@@ -99,6 +191,8 @@ __device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int t
     return *s_flag != 0;
 }
 
+// (s_flag: 4 LDS words -- [0] the wait, [1..2] the hand-off levels -- so that a slow wave still
+// reading one decision can never see the next one.)
 // Publish this workgroup's row of flux f, ticket, group reduction by the last arriver, final row
 // by the reducer of the flux's last group (all cross-workgroup accesses are agent-scope atomics).
 // (Dedicated "service" workgroups that poll the tickets and do the reductions instead were measured:
@@ -108,7 +202,7 @@ __device__ __forceinline__ void persist_publish(const PersistArgs p, const doubl
 {
     const StageArgs a = p.s;
     const int ncols = 2 * ncp;
-    const int b = blockIdx.x, nb = gridDim.x;
+    const int b = blockIdx.x, nb = p.nworkers;
     const int g = b / a.grp_size, r0 = g * a.grp_size, r1 = min(nb, r0 + a.grp_size);
     const unsigned int par = f & 1u;
     double *part = p.grp_part2 + (size_t)par * nb * a.row_stride;
@@ -126,10 +220,10 @@ __device__ __forceinline__ void persist_publish(const PersistArgs p, const doubl
     if (tid == 0) {
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: rows are read with sc1 loads
-        *s_flag = (t == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;
+        s_flag[1] = (t == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;
     }
     __syncthreads();
-    if (!*s_flag) return;
+    if (!s_flag[1]) return;
     // second level: last arriver of the group adds the group's rows in row order
     double *grow = p.grp_rows2 + ((size_t)par * PERSIST_GROUPS + g) * ncols;
     if (tid < ncols) {
@@ -150,15 +244,15 @@ __device__ __forceinline__ void persist_publish(const PersistArgs p, const doubl
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for flux f+2
         const unsigned int t2 = __hip_atomic_fetch_add(p.done2 + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        *s_flag = (t2 == (unsigned int)p.ngroups - 1u) ? 1 : 0;   // last group of this flux?
+        s_flag[2] = (t2 == (unsigned int)p.ngroups - 1u) ? 1 : 0;   // last group of this flux?
     }
     __syncthreads();
-    if (!*s_flag) return;
+    if (!s_flag[2]) return;
     // third level: add the group sums (group order) into ONE final row, so that every workgroup
     // reads 2*(ng-2) values instead of ngroups times that
+    double tot = 0.0;
     if (tid < ncols) {
         const double *src = p.grp_rows2 + (size_t)par * PERSIST_GROUPS * ncols + tid;
-        double tot = 0.0;
         for (int r = 0; r < p.ngroups; r += 32) {
             double v[32];
 #pragma unroll
@@ -166,13 +260,38 @@ __device__ __forceinline__ void persist_publish(const PersistArgs p, const doubl
 #pragma unroll
             for (int u = 0; u < 32; ++u) tot = tot + ((r + u < p.ngroups) ? v[u] : 0.0);
         }
-        st_agent(p.flux2 + (size_t)par * ncols + tid, tot);
     }
+    // several ranks: this is only the rank's row; the exchange workgroup turns it into the final one
+    double *dst = p.xch ? p.flux2 + 2 * ncols : p.flux2;
+    if (tid < ncols) st_agent(dst + (size_t)par * ncols + tid, tot);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for flux f+2
-        __hip_atomic_fetch_add(p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(p.xch ? p.ready + 4 : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The exchange workgroup (several ranks only; owns no rays): for every flux of the launch, wait for
+// the rank's row, add the rows of all ranks (xch_allsum), publish the final row.
+__device__ __forceinline__ void persist_exchange(const PersistArgs p, int *s_flag, int tid)
+{
+    const int ncols = 2 * (p.s.ng - 2);
+    const unsigned int nflux = 3u * (unsigned int)p.nsteps + 1u;
+    const XchArgs x = *p.xch;
+    const double *flux_local = p.flux2 + 2 * ncols;
+    for (unsigned int f = 0; f < nflux; ++f) {
+        const unsigned int par = f & 1u;
+        if (!persist_wait(p, f + 1u, s_flag + par, tid, p.ready + 4)) return;
+        const double mine = (tid < ncols) ? ld_agent(flux_local + (size_t)par * ncols + tid) : 0.0;
+        double tot = 0.0;
+        if (!xch_allsum(x.nranks, x.rank, x.stride, x.rows, x.flags, x.seq + f + 1ull, p.status, x.timeout_ticks,
+                        ncols, tid, s_flag + 2 + par, mine, tot))
+            return;
+        if (tid < ncols) st_agent(p.flux2 + (size_t)par * ncols + tid, tot);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -263,6 +382,10 @@ __global__ void __launch_bounds__(BLOCK) k_rk3_persist(const PersistArgs p)
     L.F = L.rows; L.u = L.F + 2 * ng; L.v = L.u + nc; L.du = L.v + nc; L.dv = L.du + ni;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (p.xch && (int)blockIdx.x == p.nworkers) {              // the exchange workgroup
+        persist_exchange(p, reinterpret_cast<int *>(lds), tid);
+        return;
+    }
     const long long start = (long long)blockIdx.x * a.rays_per_block;
     const long long end = min(a.n, start + a.rays_per_block);
 
@@ -313,6 +436,46 @@ __global__ void __launch_bounds__(BLOCK) k_rk3_persist(const PersistArgs p)
         p.dudz[i] = t.x; p.dvdz[i] = t.z;
         if (i < ni - 1) { p.slu[i] = t.y; p.slv[i] = t.w; }
     }
+}
+
+// Self-test of the node-level exchange, run once by every rank when the communicator is set up:
+// `rounds` node-level sums of known rows through the very code path of the persistent kernel.  A rank
+// that cannot see the others' rows (or sees them out of order) reports 0 and the host side falls
+// back to the all-reduce launch chain on every rank.
+struct XchTestArgs {
+    int nranks, rank, stride, rounds;
+    double *rows;
+    unsigned long long *flags;
+    unsigned long long timeout_ticks;
+    int *result;                  // 1 = every round summed to the expected value
+};
+
+__device__ __forceinline__ double xch_test_value(int rank, int round, int col)
+{
+    return (double)(rank + 1) * 1048576.0 + (double)round * 1024.0 + (double)col + 0.5;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_xch_selftest(const XchTestArgs t)
+{
+    __shared__ int s_flag[4];
+    const int tid = threadIdx.x;
+    const int ncols = min(t.stride, BLOCK);
+    int good = 1;
+    for (int round = 1; round <= t.rounds; ++round) {
+        double tot = 0.0;
+        if (!xch_allsum(t.nranks, t.rank, t.stride, t.rows, t.flags, (u64_t)round, nullptr, t.timeout_ticks, ncols,
+                        tid, s_flag + (round & 1), xch_test_value(t.rank, round, tid), tot)) {
+            good = 0;
+            break;
+        }
+        if (tid < ncols) {
+            double want = 0.0;
+            for (int r = 0; r < t.nranks; ++r) want = want + xch_test_value(r, round, tid);
+            if (tot != want) good = 0;
+        }
+    }
+    const int all_good = __syncthreads_and(good);
+    if (tid == 0) *t.result = all_good ? 1 : 0;
 }
 
 }   // namespace msgw
