@@ -1291,6 +1291,7 @@ void xch_setup(msgw_ctx *c, const void *id128, std::string &why)
 {
     xch_teardown(c);
     c->xch_seq = 0;
+    if (c->nranks > 64) { why = "more than 64 ranks (one polling lane per rank)"; return; }   // the same on every rank
     if (hipMalloc(&c->xch_scratch, 256) != hipSuccess) { (void)hipGetLastError(); why = "hipMalloc"; return; }
     // the name is derived from the communicator's unique id (FNV-1a), identical on all ranks
     unsigned long long hsh = 1469598103934665603ull;
