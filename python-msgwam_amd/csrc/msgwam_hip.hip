@@ -81,6 +81,7 @@ constexpr unsigned int XCH_MAGIC = 0x4d534758u;                 // "MSGX"
 constexpr size_t XCH_FLAGS_OFF = 4096;                          // [nranks][8] u64, one 64-byte line per rank
 constexpr unsigned long long XCH_TIMEOUT_TICKS = 2000000000ull; // 20 s of wall clock (100 MHz): ranks start apart
 constexpr int XCH_TEST_ROUNDS = 6;
+constexpr size_t PDONE_WORDS = 128 + (size_t)2 * msgw::PERSIST_GROUPS * msgw::TICKET_STRIDE;   // counters of the persistent kernel
 
 struct msgw_ctx {
     int device = 0;
@@ -134,8 +135,9 @@ struct msgw_ctx {
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_flux[2] = {nullptr, nullptr};
     // persistent RK3 kernel (single rank, coupled)
     int persist = 1;                 // 0 disables (MSGW_PERSIST=0 or after a time-out)
+    int service = 1;                 // reducer workgroups beside the workers (MSGW_SERVICE=0: last arriver reduces)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
-    unsigned int *pdone = nullptr;   // [0] ready, [1] status, [2..3] done2, [4] local_ready, [64..191] group tickets
+    unsigned int *pdone = nullptr;   // PDONE_WORDS: [0] ready, [1] status, [4] local_ready, [32..33] done2, [128..] group tickets
     double *flux2 = nullptr;         // [2][ncols] final flux rows of the persistent kernel
     unsigned long long *pstamps = nullptr;   // diagnostic builds only
     double *grp_part2 = nullptr;     // [2][blocks][row_stride]
@@ -324,7 +326,7 @@ int ensure_groups(msgw_ctx *c)
         HIPCHK(c, hipMalloc(&c->grp_rows, sizeof(double) * (size_t)2 * FUSE_ROWS * 2 * (c->ng - 2)));   // x2: flux parity
         HIPCHK(c, hipMalloc(&c->grp_cnt, sizeof(unsigned int) * 64));
         HIPCHK(c, hipMalloc(&c->grp_rows2, sizeof(double) * (size_t)2 * PERSIST_GROUPS * 2 * (c->ng - 2)));
-        HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * 256));
+        HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * PDONE_WORDS));
         HIPCHK(c, hipMalloc(&c->flux2, sizeof(double) * (size_t)4 * 2 * (c->ng - 2)));   // [2] final + [2] this rank's
     }
     HIPCHK(c, hipMemsetAsync(c->grp_cnt, 0, sizeof(unsigned int) * 64, c->stream));
@@ -535,11 +537,16 @@ int launch_persist_t(msgw_ctx *c, PersistArgs &pa, bool *resident)
     if (int rc = ensure_lds(c, k, lds)) return rc;
     int per_cu = 0;
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, BLOCK, lds));
-    const int grid = c->blocks + (pa.xch ? 1 : 0);             // + the exchange workgroup
-    *resident = (long long)per_cu * c->ncu >= grid && grid <= 2048;             // every workgroup co-resident
-    if (!*resident) return MSGW_OK;
     pa.s.grp_size = (c->blocks + PERSIST_GROUPS - 1) / PERSIST_GROUPS;
     pa.ngroups = (c->blocks + pa.s.grp_size - 1) / pa.s.grp_size;
+    // reducer workgroups (one per group) when they fit beside the workers, else the last arriver reduces
+    const long long slots = (long long)per_cu * c->ncu;
+    pa.nservice = (c->service && c->blocks + pa.ngroups + (pa.xch ? 1 : 0) <= slots && pa.ngroups > 1) ? pa.ngroups : 0;
+    pa.opts = pa.nservice ? 0u : PERSIST_OPT_PRIO;
+    if (const char *e = std::getenv("MSGW_PRIO")) pa.opts = std::atoi(e) ? PERSIST_OPT_PRIO : 0u;
+    const int grid = c->blocks + pa.nservice + (pa.xch ? 1 : 0);   // + reducers + the exchange workgroup
+    *resident = slots >= grid && grid <= 2048;                 // every workgroup co-resident
+    if (!*resident) return MSGW_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->time_next) {
         hipEvent_t *ev = timing_events(c);
@@ -568,9 +575,9 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.flux2 = c->flux2;
     pa.ready = c->pdone;
     pa.status = reinterpret_cast<int *>(c->pdone + 1);
-    pa.done2 = c->pdone + 2;
+    pa.done2 = c->pdone + 32;
     pa.nworkers = c->blocks;
-    pa.grp_cnt2 = c->pdone + 64;
+    pa.grp_cnt2 = c->pdone + 128;
 #ifdef MSGW_STAMP
     if (!c->pstamps) HIPCHK(c, hipMalloc(&c->pstamps, sizeof(unsigned long long) * 4096 * PSTAMP_PASSES * 4));
     HIPCHK(c, hipMemsetAsync(c->pstamps, 0, sizeof(unsigned long long) * 4096 * PSTAMP_PASSES * 4, c->stream));
@@ -590,7 +597,7 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.cin = ColIn{c->uu, c->vv, c->q_uu, c->q_vv};
     pa.cout = ColOut{c->uu, c->vv, c->q_uu, c->q_vv};
     pa.dudz = c->dudz; pa.dvdz = c->dvdz; pa.slu = c->slu; pa.slv = c->slv;
-    HIPCHK(c, hipMemsetAsync(c->pdone, 0, sizeof(unsigned int) * 256, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pdone, 0, sizeof(unsigned int) * PDONE_WORDS, c->stream));
     bool resident = false;
     c->time_next = time_kernels;
     int rc = MSGW_OK;
@@ -841,6 +848,7 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     c->cnt.ngrid = ngrid;
     c->cnt.nranks = 1;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
+    if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
     *out = c;
     return MSGW_OK;
 }

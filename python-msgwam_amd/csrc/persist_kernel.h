@@ -44,7 +44,10 @@
 
 namespace msgw {
 
+constexpr unsigned int PERSIST_OPT_PRIO = 1u;   // workgroups that trail by a pass run it at raised wave priority
 constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
+constexpr int TICKET_STRIDE = 32;        // unsigned ints between two tickets: pollers and arrivers of different
+                                         // groups never share a cache line
 
 // Node-level exchange: fine-grained host memory mapped by all ranks.  Read by the exchange
 // workgroup only, so it lives in device memory instead of widening every workgroup's arguments.
@@ -65,12 +68,16 @@ struct PersistArgs {
     double *grp_part2;            // [2][workgroups][row_stride]   workgroup rows, by flux parity
     double *grp_rows2;            // [2][PERSIST_GROUPS][2*(ng-2)] group sums, by flux parity
     double *flux2;                // [2][2*(ng-2)]                 final flux row, by flux parity
-    unsigned int *grp_cnt2;       // [2][64] arrival tickets of the groups   (zero at launch)
+    unsigned int *grp_cnt2;       // [2][PERSIST_GROUPS][TICKET_STRIDE] arrival tickets of the groups, one
+                                  // 128-byte line each (zero at launch)
     unsigned int *done2;          // [2] completed groups of a flux          (zero at launch)
     unsigned int *ready;          // fluxes whose final row is published     (zero at launch)
                                   // several ranks: ready[4] counts the fluxes whose LOCAL row is complete and
                                   // flux2 + 2 * 2*(ng-2) holds [2][2*(ng-2)] this rank's rows, by flux parity
-    int nworkers;                 // workgroups that own rays (the grid has one more when xch is set)
+    int nworkers;                 // workgroups that own rays
+    int nservice;                 // 0, or ngroups reducer workgroups without rays after the workers (then the
+                                  // exchange workgroup, when xch is set)
+    unsigned int opts;            // PERSIST_OPT_*
     int *status;                  // 0 ok, 1 a wait timed out
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
     const struct XchArgs *xch;    // several ranks: the node-level exchange (device memory); else nullptr
@@ -169,7 +176,9 @@ __device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int t
     if (tid == 0) {
         int ok = 1;
         if (!counter) counter = p.ready;
-        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        const unsigned int seen = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen > target) ok = 3;                             // bit 1: the next flux is final too, i.e. this workgroup trails
+        if (seen < target) {
             const unsigned long long t0 = wall_clock64();
             while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(8);
@@ -188,43 +197,25 @@ __device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int t
         *s_flag = ok;
     }
     __syncthreads();
-    return *s_flag != 0;
+    const int r = *s_flag;
+    // A workgroup that finds the NEXT flux final as well is a pass behind the others, and those are
+    // waiting for it: it runs the coming pass at raised wave priority (with the last arriver reducing:
+    // 77.8 -> 72.7 us per step; no gain with reducer workgroups, so only used without them).
+    if (p.opts & PERSIST_OPT_PRIO) {
+        if (r & 2) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+    return r != 0;
 }
 
-// (s_flag: 4 LDS words -- [0] the wait, [1..2] the hand-off levels -- so that a slow wave still
-// reading one decision can never see the next one.)
-// Publish this workgroup's row of flux f, ticket, group reduction by the last arriver, final row
-// by the reducer of the flux's last group (all cross-workgroup accesses are agent-scope atomics).
-// (Dedicated "service" workgroups that poll the tickets and do the reductions instead were measured:
-// publishing got slower and the period rose from 26.5 to 31 us per pass, so the last arriver reduces.)
-__device__ __forceinline__ void persist_publish(const PersistArgs p, const double *rows, int ncp, int *s_flag,
-                                                int tid, unsigned int f)
+// Second level: add the rows of group g (flux f) in row order into the group's row.
+__device__ __forceinline__ void persist_reduce_group(const PersistArgs p, int g, unsigned int f, int ncols, int tid)
 {
     const StageArgs a = p.s;
-    const int ncols = 2 * ncp;
-    const int b = blockIdx.x, nb = p.nworkers;
-    const int g = b / a.grp_size, r0 = g * a.grp_size, r1 = min(nb, r0 + a.grp_size);
+    const int nb = p.nworkers;
+    const int r0 = g * a.grp_size, r1 = min(nb, r0 + a.grp_size);
     const unsigned int par = f & 1u;
-    double *part = p.grp_part2 + (size_t)par * nb * a.row_stride;
-    unsigned int *ticket = p.grp_cnt2 + par * 64 + g;
-    __syncthreads();                                          // all waves' rows complete in LDS
-    double *mine = part + (size_t)b * a.row_stride;
-    for (int col = tid; col < ncols; col += BLOCK) {
-        double acc = rows[col];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) acc = acc + rows[w * ncols + col];
-        st_agent(mine + col, acc);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: rows are read with sc1 loads
-        s_flag[1] = (t == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_flag[1]) return;
-    // second level: last arriver of the group adds the group's rows in row order
+    const double *part = p.grp_part2 + (size_t)par * nb * a.row_stride;
     double *grow = p.grp_rows2 + ((size_t)par * PERSIST_GROUPS + g) * ncols;
     if (tid < ncols) {
         const double *src = part + tid;
@@ -240,16 +231,13 @@ __device__ __forceinline__ void persist_publish(const PersistArgs p, const doubl
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for flux f+2
-        const unsigned int t2 = __hip_atomic_fetch_add(p.done2 + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        s_flag[2] = (t2 == (unsigned int)p.ngroups - 1u) ? 1 : 0;   // last group of this flux?
-    }
-    __syncthreads();
-    if (!s_flag[2]) return;
-    // third level: add the group sums (group order) into ONE final row, so that every workgroup
-    // reads 2*(ng-2) values instead of ngroups times that
+}
+
+// Third level: add the group sums (group order) into ONE final row, so that every workgroup reads
+// 2*(ng-2) values instead of ngroups times that; then announce it.
+__device__ __forceinline__ void persist_reduce_final(const PersistArgs p, unsigned int f, int ncols, int tid)
+{
+    const unsigned int par = f & 1u;
     double tot = 0.0;
     if (tid < ncols) {
         const double *src = p.grp_rows2 + (size_t)par * PERSIST_GROUPS * ncols + tid;
@@ -269,6 +257,100 @@ __device__ __forceinline__ void persist_publish(const PersistArgs p, const doubl
     if (tid == 0) {
         __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for flux f+2
         __hip_atomic_fetch_add(p.xch ? p.ready + 4 : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Publish this workgroup's row of flux f, take a ticket; the LAST arriver of a group adds the group's
+// rows, the reducer of the flux's last group adds the group sums (all cross-workgroup accesses are
+// agent-scope atomics).  s_flag words [1], [2]: the two hand-off decisions ([0] is the wait's), so
+// that a slow wave still reading one decision can never see the next one.
+// With reducer workgroups (p.nservice, the default when they fit) the workgroup only takes its
+// ticket.  Also measured: reductions as duties of the oldest, mostly idle ray workgroups, done inside
+// their wait loop -- the reduce chain then reacts only when a reducer happens to be waiting, picks up
+// ~10 us of polling latency and gates everybody (80 -> 88.6 us per step); and phase-staggering the
+// dispatch rounds by up to half a pass at launch (no effect: the offsets relax within a few passes).
+__device__ __forceinline__ void persist_publish(const PersistArgs p, const double *rows, int ncp, int *s_flag,
+                                                int tid, unsigned int f)
+{
+    const StageArgs a = p.s;
+    const int ncols = 2 * ncp;
+    const int b = blockIdx.x, nb = p.nworkers;
+    const int g = b / a.grp_size, r0 = g * a.grp_size, r1 = min(nb, r0 + a.grp_size);
+    const unsigned int par = f & 1u;
+    double *part = p.grp_part2 + (size_t)par * nb * a.row_stride;
+    unsigned int *ticket = p.grp_cnt2 + ((size_t)par * PERSIST_GROUPS + g) * TICKET_STRIDE;
+    __syncthreads();                                          // all waves' rows complete in LDS
+    double *mine = part + (size_t)b * a.row_stride;
+    for (int col = tid; col < ncols; col += BLOCK) {
+        double acc = rows[col];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) acc = acc + rows[w * ncols + col];
+        st_agent(mine + col, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
+    __syncthreads();
+    if (p.nservice) {                                         // the group's reducer workgroup takes it from here
+        if (tid == 0) __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: rows are read with sc1 loads
+        s_flag[1] = (t == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_flag[1]) return;
+    persist_reduce_group(p, g, f, ncols, tid);
+    if (tid == 0) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for flux f+2
+        const unsigned int t2 = __hip_atomic_fetch_add(p.done2 + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        s_flag[2] = (t2 == (unsigned int)p.ngroups - 1u) ? 1 : 0;   // last group of this flux?
+    }
+    __syncthreads();
+    if (!s_flag[2]) return;
+    persist_reduce_final(p, f, ncols, tid);
+}
+
+// Reducer workgroup of group g (owns no rays; p.nservice of them run beside the workers): for every
+// flux of the launch wait until the group's rows have all arrived, add them, and -- the reducer that
+// completes a flux -- add the group sums into the final row.  This takes ~6.5 us of serial L2 round
+// trips per pass off the LAST ARRIVER, which is the workgroup everybody else is waiting for
+// (tools/persist_timeline.py).  Each reducer polls its own ticket on its own cache line.
+__device__ __forceinline__ void persist_service(const PersistArgs p, int g, int *s_flag, int tid)
+{
+    const int ncols = 2 * (p.s.ng - 2);
+    const unsigned int nflux = 3u * (unsigned int)p.nsteps + 1u;
+    const unsigned int gsize = (unsigned int)(min(p.nworkers, (g + 1) * p.s.grp_size) - g * p.s.grp_size);
+    for (unsigned int f = 0; f < nflux; ++f) {
+        const unsigned int par = f & 1u;
+        unsigned int *ticket = p.grp_cnt2 + ((size_t)par * PERSIST_GROUPS + g) * TICKET_STRIDE;
+        if (tid == 0) {
+            int ok = 1;
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gsize) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > p.timeout_ticks ||
+                    __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: rows are read with sc1 loads
+            s_flag[par] = ok;
+        }
+        __syncthreads();
+        if (!s_flag[par]) return;
+        persist_reduce_group(p, g, f, ncols, tid);
+        if (tid == 0) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for flux f+2
+            const unsigned int t2 = __hip_atomic_fetch_add(p.done2 + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            s_flag[2 + par] = (t2 == (unsigned int)p.ngroups - 1u) ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_flag[2 + par]) persist_reduce_final(p, f, ncols, tid);
     }
 }
 
@@ -365,7 +447,7 @@ __device__ __forceinline__ bool persist_stage(const PersistArgs p, const Persist
 }
 
 template <bool SAT, bool FVEC, bool DIRECT>
-__global__ void __launch_bounds__(BLOCK) k_rk3_persist(const PersistArgs p)
+__global__ void __launch_bounds__(BLOCK, 4) k_rk3_persist(const PersistArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const StageArgs a = p.s;
@@ -382,8 +464,19 @@ __global__ void __launch_bounds__(BLOCK) k_rk3_persist(const PersistArgs p)
     L.F = L.rows; L.u = L.F + 2 * ng; L.v = L.u + nc; L.du = L.v + nc; L.dv = L.du + ni;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (p.xch && (int)blockIdx.x == p.nworkers) {              // the exchange workgroup
-        persist_exchange(p, reinterpret_cast<int *>(lds), tid);
+#ifdef MSGW_STAMP
+    const unsigned int hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+    const unsigned int xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+    if (tid == 0 && p.pstamps) {                               // where does this workgroup run?
+        p.pstamps[((size_t)blockIdx.x * PSTAMP_PASSES + (PSTAMP_PASSES - 1)) * 4 + 0] = hw_id;
+        p.pstamps[((size_t)blockIdx.x * PSTAMP_PASSES + (PSTAMP_PASSES - 1)) * 4 + 1] = xcc_id;
+    }
+#endif
+    if ((int)blockIdx.x >= p.nworkers) {                       // workgroups without rays
+        const int s = (int)blockIdx.x - p.nworkers;
+        __builtin_amdgcn_s_setprio(3);                         // they only ever poll and reduce: react at once
+        if (s < p.nservice) persist_service(p, s, reinterpret_cast<int *>(lds), tid);
+        else persist_exchange(p, reinterpret_cast<int *>(lds), tid);
         return;
     }
     const long long start = (long long)blockIdx.x * a.rays_per_block;

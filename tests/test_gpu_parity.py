@@ -346,6 +346,16 @@ def test_persistent_kernel_equals_per_stage_kernels(monkeypatch):
         outs[persist] = gpu_state(p, st)
         assert p.counters()["persist_steps"] == (40 if persist == "1" else 0)
         p.close()
+    # reducer workgroups (default) or the last arriver of each group: same rows, same order
+    monkeypatch.setenv("MSGW_SERVICE", "0")
+    p = make_prop(s, st)
+    p.step(60.0, 3)
+    p.step(60.0, 40)
+    alt = gpu_state(p, st)
+    assert p.counters()["persist_steps"] == 40
+    p.close()
+    for k, a, b in zip(STATE_KEYS, alt, outs["1"]):
+        assert np.array_equal(a, b, equal_nan=True), f"last-arriver reduction differs from the reducer workgroups in {k}"
     # the two paths group the workgroup rows differently (16 vs 32 groups), so they agree to
     # summation-order noise, not bit for bit
     check_state(outs["1"], outs["0"], 1e-11, 1e-11, "persist-vs-per-stage")

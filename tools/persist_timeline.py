@@ -34,3 +34,40 @@ for q in range(0, 10):
     print(line)
 d_wait = np.median(T[:, 3:9, 1] - T[:, 3:9, 0]); d_tiles = np.median(T[:, 3:9, 2] - T[:, 3:9, 1]); d_pub = np.median(T[:, 3:9, 3] - T[:, 3:9, 2])
 print(f"median per pass: wait+column {d_wait:.2f} us, tiles {d_tiles:.2f} us, publish {d_pub:.2f} us; pass period {(np.median(T[:, 9, 0]) - np.median(T[:, 3, 0])) / 6:.2f} us")
+# per-workgroup detail of one steady pass: by dispatch round (workgroup index // 256)
+q = 6
+for rnd in range((nb + 255) // 256):
+    sel = np.arange(len(T)) // 256 == rnd
+    if not sel.any():
+        continue
+    base = np.median(T[:, q, 0])
+    print(f"round {rnd}: start {np.median(T[sel, q, 0]) - base:6.2f}  column {np.median(T[sel, q, 1] - T[sel, q, 0]):5.2f}  "
+          f"tiles {np.median(T[sel, q, 2] - T[sel, q, 1]):5.2f}  publish {np.median(T[sel, q, 3] - T[sel, q, 2]):5.2f}  "
+          f"end {np.median(T[sel, q, 3]) - base:6.2f}")
+# idle estimate: gap between a workgroup's publish end and its next pass start, and wait inside column
+print("gap publish->next start (median)", np.median(T[:, 4:9, 0] - T[:, 3:8, 3]))
+# which workgroups are the stragglers?
+q = 6
+dur = T[:, q, 2] - T[:, q, 1]
+order = np.argsort(-T[:, q, 0])
+print("latest starters of pass", q, ":", [(int(i), round(float(T[i, q, 0] - np.median(T[:, q, 0])), 1), round(float(dur[i]), 1)) for i in order[:24]])
+late = np.sort(order[:48])
+print("late set indices:", late.tolist())
+print("tiles duration by index decile:", [round(float(np.median(dur[k * len(dur) // 10:(k + 1) * len(dur) // 10])), 1) for k in range(10)])
+pub = T[:, q, 3] - T[:, q, 2]
+print("publish > 4us:", np.nonzero(pub > 4)[0].tolist()[:64])
+hw = buf[:, NP - 1, 0].astype(np.int64); xcc = buf[:, NP - 1, 1].astype(np.int64) & 0xf
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
+cuid = xcc * 1000 + se * 100 + sh * 10 + cu
+print("xcc of workgroups 0..15:", xcc[:16].tolist())
+for x in range(8):
+    sel = xcc == x
+    print(f"xcc {x}: workgroups {int(sel.sum())}, distinct CUs {len(np.unique(cuid[sel]))}, max per CU {np.bincount(np.unique(cuid[sel], return_inverse=True)[1]).max()}, "
+          f"tiles median {np.median(dur[sel]):.1f} us, start offset {np.median(T[sel, q, 0]) - np.median(T[:, q, 0]):.1f} us")
+# breakdown of the trailing cohort (latest 5 % starters of pass q) vs everybody
+late = order[:max(len(order) // 20, 8)]
+for name, sel in (("trailing 5%", late), ("all", np.arange(len(T)))):
+    print(f"{name:12s}: start {np.median(T[sel, q, 0]) - np.median(T[:, q, 0]):6.2f}  wait+column {np.median(T[sel, q, 1] - T[sel, q, 0]):5.2f}  "
+          f"tiles {np.median(T[sel, q, 2] - T[sel, q, 1]):5.2f}  publish {np.median(T[sel, q, 3] - T[sel, q, 2]):5.2f}  "
+          f"period {np.median(T[sel, q + 1, 0] - T[sel, q, 0]):5.2f}  xcc {np.bincount(xcc[sel], minlength=8).tolist()}  round {np.bincount(sel // 256, minlength=4).tolist()}")
+print("publish max", float(pub.max()), "at", int(pub.argmax()), " publish > 4us count", int((pub > 4).sum()))

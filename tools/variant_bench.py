@@ -1,0 +1,29 @@
+"""GPU box: step time of the kernel variants (online saturation, direct saturation, per-ray latitude)
+through the persistent kernel and through the per-stage launch chain, bench workload."""
+import os, sys, time
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "python-msgwam_amd"))
+import numpy as np
+import bench
+from msgwam_amd import _capi
+from msgwam_amd.spectrum import gaussian_spectrum
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+lprop, grid, grids, uu, vv = bench.column(101)
+sp = gaussian_spectrum(n, grids, lprop.rhobar, alpha=0.01)
+rng = np.random.default_rng(0)
+for name, sat, flags, vec in (("plain", False, 0, False), ("online sat", True, 0, False), ("direct sat", False, _capi.DIRECT_SAT_QUIRK, False),
+                              ("latitude", False, 0, True), ("sat+latitude", True, 0, True), ("direct+latitude", False, _capi.DIRECT_SAT_QUIRK, True)):
+    res = []
+    for persist in ("1", "0"):
+        os.environ["MSGW_PERSIST"] = persist
+        p = _capi.Propagator(101, n)
+        p.set_config(0.01, 0.0, 1.0, sat)
+        p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, uu, vv)
+        phi = rng.uniform(-0.5, 0.5, n) if vec else sp["phi"]
+        p.upload_rays(sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], phi, sp["dkk"], sp["dll"], sp["area"])
+        p.set_tuning(4, 4)
+        p.step(120.0, 20, flags); p.sync()
+        t0 = time.perf_counter(); p.step(120.0, 100, flags); p.sync(); dt = time.perf_counter() - t0
+        res.append((dt / 100 * 1e6, p.counters()["persist_steps"]))
+        p.close()
+    print(f"{name:16s}: persistent {res[0][0]:7.1f} us/step (persist_steps {res[0][1]})   chain {res[1][0]:7.1f} us/step")
