@@ -137,8 +137,9 @@ struct msgw_ctx {
     int persist = 1;                 // 0 disables (MSGW_PERSIST=0 or after a time-out)
     int service = 1;                 // reducer workgroups beside the workers (MSGW_SERVICE=0: last arriver reduces)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
-    unsigned int *pdone = nullptr;   // PDONE_WORDS: [0] ready, [1] status, [4] local_ready, [32..33] done2, [128..] group tickets
+    unsigned int *pdone = nullptr;   // PDONE_WORDS: [0] ready, [1] status, [32..33] done2, [64] final rows, [96] rank rows, [128..] group tickets
     double *flux2 = nullptr;         // [2][ncols] final flux rows of the persistent kernel
+    double *shtab = nullptr;         // [2][ng-2] double4 shear tables published by the column workgroup
     unsigned long long *pstamps = nullptr;   // diagnostic builds only
     double *grp_part2 = nullptr;     // [2][blocks][row_stride]
     size_t grp_part2_elems = 0;
@@ -328,6 +329,7 @@ int ensure_groups(msgw_ctx *c)
         HIPCHK(c, hipMalloc(&c->grp_rows2, sizeof(double) * (size_t)2 * PERSIST_GROUPS * 2 * (c->ng - 2)));
         HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * PDONE_WORDS));
         HIPCHK(c, hipMalloc(&c->flux2, sizeof(double) * (size_t)4 * 2 * (c->ng - 2)));   // [2] final + [2] this rank's
+        HIPCHK(c, hipMalloc(&c->shtab, sizeof(double) * (size_t)2 * 4 * (c->ng - 2)));
     }
     HIPCHK(c, hipMemsetAsync(c->grp_cnt, 0, sizeof(unsigned int) * 64, c->stream));
     return MSGW_OK;
@@ -541,10 +543,11 @@ int launch_persist_t(msgw_ctx *c, PersistArgs &pa, bool *resident)
     pa.ngroups = (c->blocks + pa.s.grp_size - 1) / pa.s.grp_size;
     // reducer workgroups (one per group) when they fit beside the workers, else the last arriver reduces
     const long long slots = (long long)per_cu * c->ncu;
-    pa.nservice = (c->service && c->blocks + pa.ngroups + (pa.xch ? 1 : 0) <= slots && pa.ngroups > 1) ? pa.ngroups : 0;
+    pa.nservice = (c->service && c->blocks + pa.ngroups + 1 + (pa.xch ? 1 : 0) <= slots) ? pa.ngroups : 0;
     pa.opts = pa.nservice ? 0u : PERSIST_OPT_PRIO;
     if (const char *e = std::getenv("MSGW_PRIO")) pa.opts = std::atoi(e) ? PERSIST_OPT_PRIO : 0u;
-    const int grid = c->blocks + pa.nservice + (pa.xch ? 1 : 0);   // + reducers + the exchange workgroup
+    // + reducer workgroups + the column workgroup + the exchange workgroup
+    const int grid = c->blocks + pa.nservice + (pa.nservice ? 1 : 0) + (pa.xch ? 1 : 0);
     *resident = slots >= grid && grid <= 2048;                 // every workgroup co-resident
     if (!*resident) return MSGW_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -573,6 +576,7 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.grp_rows2 = c->grp_rows2;
     pa.grp_part2 = c->grp_part2;
     pa.flux2 = c->flux2;
+    pa.shtab = c->shtab;
     pa.ready = c->pdone;
     pa.status = reinterpret_cast<int *>(c->pdone + 1);
     pa.done2 = c->pdone + 32;
@@ -873,6 +877,7 @@ int msgw_destroy(msgw_ctx *c)
     if (c->grp_rows2) (void)hipFree(c->grp_rows2);
     if (c->pdone) (void)hipFree(c->pdone);
     if (c->flux2) (void)hipFree(c->flux2);
+    if (c->shtab) (void)hipFree(c->shtab);
     if (c->grp_part2) (void)hipFree(c->grp_part2);
     for (int i = 0; i < 2; ++i) {
         if (c->ev_rows[i]) (void)hipEventDestroy(c->ev_rows[i]);

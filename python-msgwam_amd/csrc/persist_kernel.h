@@ -46,6 +46,8 @@ namespace msgw {
 
 constexpr unsigned int PERSIST_OPT_PRIO = 1u;   // workgroups that trail by a pass run it at raised wave priority
 constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
+constexpr int PD_ROW = 64;               // ready[PD_ROW]: fluxes whose final row is in flux2 (own cache line)
+constexpr int PD_LOCAL = 96;             // ready[PD_LOCAL]: several ranks: fluxes whose rank row is complete
 constexpr int TICKET_STRIDE = 32;        // unsigned ints between two tickets: pollers and arrivers of different
                                          // groups never share a cache line
 
@@ -71,12 +73,14 @@ struct PersistArgs {
     unsigned int *grp_cnt2;       // [2][PERSIST_GROUPS][TICKET_STRIDE] arrival tickets of the groups, one
                                   // 128-byte line each (zero at launch)
     unsigned int *done2;          // [2] completed groups of a flux          (zero at launch)
-    unsigned int *ready;          // fluxes whose final row is published     (zero at launch)
-                                  // several ranks: ready[4] counts the fluxes whose LOCAL row is complete and
+    unsigned int *ready;          // passes that may start: the column has been advanced with that many fluxes
+                                  // (zero at launch); ready[PD_ROW] counts the fluxes whose final row is in flux2
+                                  // several ranks: ready[PD_LOCAL] counts the fluxes whose LOCAL row is complete and
                                   // flux2 + 2 * 2*(ng-2) holds [2][2*(ng-2)] this rank's rows, by flux parity
     int nworkers;                 // workgroups that own rays
-    int nservice;                 // 0, or ngroups reducer workgroups without rays after the workers (then the
-                                  // exchange workgroup, when xch is set)
+    int nservice;                 // 0, or ngroups reducer workgroups without rays after the workers, followed by
+                                  // ONE column workgroup (then the exchange workgroup, when xch is set)
+    double *shtab;                // [2][ng-2] double4: shear table of a pass, by flux parity (column workgroup)
     unsigned int opts;            // PERSIST_OPT_*
     int *status;                  // 0 ok, 1 a wait timed out
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
@@ -169,14 +173,14 @@ __device__ __forceinline__ bool xch_allsum(int nranks, int rank, int stride, dou
     return true;
 }
 
-// Wait until *ready >= target stages (one lane polls, bounded), then release the workgroup.
-__device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int target, int *s_flag, int tid,
-                                             const unsigned int *counter = nullptr)
+// Wait until *counter >= target (one lane polls, bounded), then release the workgroup.  `seen` is
+// a value of the counter that lane 0 has already loaded (see persist_stage: the first poll is issued
+// BEFORE the tile loads, so its result does not wait for them -- memory returns in order).
+__device__ __forceinline__ bool persist_wait_seen(const PersistArgs p, unsigned int target, unsigned int seen,
+                                                  int *s_flag, int tid, const unsigned int *counter)
 {
     if (tid == 0) {
         int ok = 1;
-        if (!counter) counter = p.ready;
-        const unsigned int seen = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (seen > target) ok = 3;                             // bit 1: the next flux is final too, i.e. this workgroup trails
         if (seen < target) {
             const unsigned long long t0 = wall_clock64();
@@ -206,6 +210,15 @@ __device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int t
         else __builtin_amdgcn_s_setprio(0);
     }
     return r != 0;
+}
+
+__device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int target, int *s_flag, int tid,
+                                             const unsigned int *counter = nullptr)
+{
+    if (!counter) counter = p.ready;
+    unsigned int seen = 0;
+    if (tid == 0) seen = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return persist_wait_seen(p, target, seen, s_flag, tid, counter);
 }
 
 // Second level: add the rows of group g (flux f) in row order into the group's row.
@@ -256,7 +269,8 @@ __device__ __forceinline__ void persist_reduce_final(const PersistArgs p, unsign
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for flux f+2
-        __hip_atomic_fetch_add(p.xch ? p.ready + 4 : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned int *cnt = p.xch ? p.ready + PD_LOCAL : (p.nservice ? p.ready + PD_ROW : p.ready);
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -364,7 +378,7 @@ __device__ __forceinline__ void persist_exchange(const PersistArgs p, int *s_fla
     const double *flux_local = p.flux2 + 2 * ncols;
     for (unsigned int f = 0; f < nflux; ++f) {
         const unsigned int par = f & 1u;
-        if (!persist_wait(p, f + 1u, s_flag + par, tid, p.ready + 4)) return;
+        if (!persist_wait(p, f + 1u, s_flag + par, tid, p.ready + PD_LOCAL)) return;
         const double mine = (tid < ncols) ? ld_agent(flux_local + (size_t)par * ncols + tid) : 0.0;
         double tot = 0.0;
         if (!xch_allsum(x.nranks, x.rank, x.stride, x.rows, x.flags, x.seq + f + 1ull, p.status, x.timeout_ticks,
@@ -373,7 +387,8 @@ __device__ __forceinline__ void persist_exchange(const PersistArgs p, int *s_fla
         if (tid < ncols) st_agent(p.flux2 + (size_t)par * ncols + tid, tot);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0)
+            __hip_atomic_fetch_add(p.nservice ? p.ready + PD_ROW : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -415,6 +430,36 @@ __device__ __forceinline__ void persist_column(const PersistArgs p, const Persis
     __syncthreads();
 }
 
+// The column workgroup (owns no rays; runs beside the reducer workgroups): the ONLY place where the
+// mean flow advances.  For every flux of the launch: wait for its final row, apply the RK stage to
+// the column replica in LDS, derive the shear table the rays interpolate in, publish the table and
+// release the pass.  The ray workgroups then load 3.2 KB and pass one barrier instead of each
+// repeating the update (a poll, a row load, five barriers: 3.7 us on the critical path per pass).
+__device__ __forceinline__ void persist_column_wg(const PersistArgs p, const PersistLds L, int tid)
+{
+    const int ng = p.s.ng, ni = ng - 2, nc = ng - 1;
+    const unsigned int nflux = 3u * (unsigned int)p.nsteps;      // the flux of the final state is unused
+    for (unsigned int f = 0; f < nflux; ++f) {
+        if (!persist_wait(p, f + 1u, L.flag, tid, p.ready + PD_ROW)) return;
+        persist_column(p, L, f + 1u, (int)(f % 3u), tid);       // pass q = f+1 is RK stage q % 3, column stage (q+2) % 3
+        double *tab = p.shtab + (size_t)(f & 1u) * 4 * ni;
+        const double *src = reinterpret_cast<const double *>(L.sh);
+        for (int i = tid; i < 4 * ni; i += BLOCK) st_agent(tab + i, src[i]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // canonical column and derived tables at exit
+    for (int i = tid; i < nc; i += BLOCK) {
+        p.cout.uu[i] = L.cu[i]; p.cout.vv[i] = L.cv[i]; p.cout.q_uu[i] = L.cqu[i]; p.cout.q_vv[i] = L.cqv[i];
+    }
+    for (int i = tid; i < ni; i += BLOCK) {
+        const double4 t = L.sh[i];
+        p.dudz[i] = t.x; p.dvdz[i] = t.z;
+        if (i < ni - 1) { p.slu[i] = t.y; p.slv[i] = t.w; }
+    }
+}
+
 template <int STAGE, bool SAT, bool FVEC, bool DIRECT>
 __device__ __forceinline__ bool persist_stage(const PersistArgs p, const PersistLds L, unsigned int q,
                                               long long start, long long end, int tid, int wave, int lane)
@@ -427,12 +472,21 @@ __device__ __forceinline__ bool persist_stage(const PersistArgs p, const Persist
     asm volatile("" : "+v"(tid));
     PSTAMP(q, 0);
     TileRegs cur;
-    // wave 0 polls and fences (its acquire waits for its own outstanding loads), so it loads after
-    if (wave != 0 || q == 0) load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, start, tid, end);
+    // Lane 0's first poll of `ready` is issued before its tile loads: returns are in order, so the
+    // poll's result is there after one round trip while the tile's 11 loads are still in flight.
+    unsigned int seen = 0;
+    if (q > 0 && tid == 0) seen = __hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, start, tid, end);
     if (q > 0) {
-        if (!persist_wait(p, q, L.flag, tid)) return false;
-        if (wave == 0) load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, start, tid, end);
-        persist_column(p, L, q, (STAGE + 2) % 3, tid);
+        if (!persist_wait_seen(p, q, seen, L.flag, tid, p.ready)) return false;
+        if (p.nservice) {                                      // the column workgroup has published this pass's table
+            const double *tab = p.shtab + (size_t)((q - 1u) & 1u) * 4 * (a.ng - 2);
+            double *dst = reinterpret_cast<double *>(L.sh);
+            for (int i = tid; i < 4 * (a.ng - 2); i += BLOCK) dst[i] = ld_agent(tab + i);
+            __syncthreads();
+        } else {
+            persist_column(p, L, q, (STAGE + 2) % 3, tid);
+        }
     }
     PSTAMP(q, 1);
     for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
@@ -472,13 +526,12 @@ __global__ void __launch_bounds__(BLOCK, 4) k_rk3_persist(const PersistArgs p)
         p.pstamps[((size_t)blockIdx.x * PSTAMP_PASSES + (PSTAMP_PASSES - 1)) * 4 + 1] = xcc_id;
     }
 #endif
-    if ((int)blockIdx.x >= p.nworkers) {                       // workgroups without rays
-        const int s = (int)blockIdx.x - p.nworkers;
+    const int role = (int)blockIdx.x - p.nworkers;             // >= 0: a workgroup without rays
+    if (role >= 0) {
         __builtin_amdgcn_s_setprio(3);                         // they only ever poll and reduce: react at once
-        if (s < p.nservice) persist_service(p, s, reinterpret_cast<int *>(lds), tid);
-        else persist_exchange(p, reinterpret_cast<int *>(lds), tid);
-        return;
-    }
+        if (role < p.nservice) { persist_service(p, role, reinterpret_cast<int *>(lds), tid); return; }
+        if (role > p.nservice || !p.nservice) { persist_exchange(p, reinterpret_cast<int *>(lds), tid); return; }
+    }                                                          // role == nservice > 0: the column workgroup, below
     const long long start = (long long)blockIdx.x * a.rays_per_block;
     const long long end = min(a.n, start + a.rays_per_block);
 
@@ -498,6 +551,10 @@ __global__ void __launch_bounds__(BLOCK, 4) k_rk3_persist(const PersistArgs p)
                                L.dv[i], in ? column_slope(L.dv, L.xg, i) : 0.0);
     }
     __syncthreads();
+    if (role >= 0) {
+        persist_column_wg(p, L, tid);
+        return;
+    }
 
     // deposit-only pre-pass: F_0 = wave_projection(state_0)
     {
@@ -516,8 +573,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_rk3_persist(const PersistArgs p)
         if (!persist_stage<2, SAT, FVEC, DIRECT>(p, L, q, start, end, tid, wave, lane)) return;
         ++q;
     }
-    if (blockIdx.x != 0) return;
-    // workgroup 0 applies the last update (column_q needs F_{q-1}) and writes the column back;
+    if (blockIdx.x != 0 || p.nservice) return;
+    // (no column workgroup:) workgroup 0 applies the last update (column_q needs F_{q-1}) and writes the column back;
     // F_q, published by the last pass, is not used (the next call starts with its own pre-pass)
     if (!persist_wait(p, q, L.flag, tid)) return;
     persist_column(p, L, q, 2, tid);

@@ -71,3 +71,17 @@ for name, sel in (("trailing 5%", late), ("all", np.arange(len(T)))):
           f"tiles {np.median(T[sel, q, 2] - T[sel, q, 1]):5.2f}  publish {np.median(T[sel, q, 3] - T[sel, q, 2]):5.2f}  "
           f"period {np.median(T[sel, q + 1, 0] - T[sel, q, 0]):5.2f}  xcc {np.bincount(xcc[sel], minlength=8).tolist()}  round {np.bincount(sel // 256, minlength=4).tolist()}")
 print("publish max", float(pub.max()), "at", int(pub.argmax()), " publish > 4us count", int((pub > 4).sum()))
+# steady-state averages over passes 8..14
+qs = np.arange(8, 15)
+med0 = np.median(T[:, qs, 0], axis=0)
+off = (T[:, qs, 0] - med0).mean(axis=1)
+wc = (T[:, qs, 1] - T[:, qs, 0]).mean(axis=1); tl = (T[:, qs, 2] - T[:, qs, 1]).mean(axis=1); pb = (T[:, qs, 3] - T[:, qs, 2]).mean(axis=1)
+per = (T[:, 14, 0] - T[:, 8, 0]) / 6
+o2 = np.argsort(-off)
+for name, sel in (("trailing 5%", o2[:len(o2) // 20]), ("next 20%", o2[len(o2) // 20:len(o2) // 4]), ("leading 25%", o2[-len(o2) // 4:]), ("all", o2)):
+    print(f"steady {name:12s}: start {off[sel].mean():6.2f}  wait+column {wc[sel].mean():5.2f}  tiles {tl[sel].mean():5.2f}  publish {pb[sel].mean():5.2f}  "
+          f"period {per[sel].mean():5.2f}  round {np.bincount(sel // 256, minlength=4).tolist()}  xcc {np.bincount(xcc[sel], minlength=8).tolist()}")
+# release time of each pass = earliest 'column done' ; trailing end = latest 'published'
+rel = T[:, 6:15, 1].min(axis=0); endmax = T[:, 4:13, 3].max(axis=0)
+print("release(q) - max published(q-2):", np.round(rel - endmax, 2).tolist())
+print("release period:", np.round(np.diff(rel), 2).tolist())
