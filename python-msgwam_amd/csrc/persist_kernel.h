@@ -534,6 +534,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_rk3_persist(const PersistArgs p)
     }                                                          // role == nservice > 0: the column workgroup, below
     const long long start = (long long)blockIdx.x * a.rays_per_block;
     const long long end = min(a.n, start + a.rays_per_block);
+    // (Wave priority by dispatch round, youngest highest, was measured: it inverts which workgroup of
+    // a CU finishes last -- the oldest instead of the youngest -- and leaves the period unchanged: the
+    // CU's drain time plus the last workgroup's hand-off is what counts.)
 
     for (int i = tid; i < ni; i += BLOCK) L.xg[i] = a.c.xg[i];
     for (int i = tid; i < nc; i += BLOCK) {
