@@ -58,7 +58,8 @@ typedef struct {
     int32_t blocks;              /* workgroups of the ray-stage kernel                          */
     int32_t graph_steps;         /* RK3 steps per captured graph (0 = eager)                    */
     int32_t nranks;              /* communicator size (1 = no collective)                       */
-    int32_t persist_steps;       /* RK3 steps done by the last persistent launch (0 = per-stage kernels) */
+    int32_t persist_steps;       /* RK3 steps covered by ONE launch in the last msgw_step call: persistent coupled kernel
+                                    or fused fixed-background kernel (0 = one launch per RK stage)       */
     int32_t exchange;            /* 1: multi-rank steps use the in-kernel node-level flux exchange */
 } msgw_counters_t;
 

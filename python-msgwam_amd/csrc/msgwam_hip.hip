@@ -728,10 +728,10 @@ int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_k
         c->time_next = false;
         return rc;
     };
-    if (flags & MSGW_FIXED_BACKGROUND) {
-        for (int s = 0; s < count; ++s)
-            if (int rc = timed([&] { return launch_fixed(c, sa, mode); })) return rc;
-        return MSGW_OK;
+    if (flags & MSGW_FIXED_BACKGROUND) {                       // independent rays: all steps in ONE launch
+        sa.fixed_steps = count;
+        c->cnt.persist_steps = count;
+        return timed([&] { return launch_fixed(c, sa, mode); });
     }
     const ColIn in_set[2] = {ColIn{c->uu, c->vv, c->q_uu, c->q_vv}, ColIn{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
     const ColOut out_set[2] = {ColOut{c->uu, c->vv, c->q_uu, c->q_vv}, ColOut{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
@@ -1005,7 +1005,8 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
     const bool time_kernels = (flags & MSGW_TIME_KERNELS) != 0;
     // With a real collective in the chain launches stay eager: hipGraph capture of ncclAllReduce
     // across ranks cannot be exercised on the 1-GPU development boxes, so it is not relied upon.
-    const bool eager = time_kernels || (flags & MSGW_NO_GRAPH) || c->graph_steps == 0 || c->nranks > 1;
+    const bool eager = time_kernels || (flags & MSGW_NO_GRAPH) || c->graph_steps == 0 || c->nranks > 1 ||
+                       (flags & MSGW_FIXED_BACKGROUND);      // fixed background: one launch for all steps anyway
     const unsigned gflags = flags & ~(MSGW_NO_GRAPH | MSGW_TIME_KERNELS);
     if (time_kernels) c->kev_used = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));

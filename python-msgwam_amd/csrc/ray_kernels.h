@@ -40,6 +40,7 @@ struct StageArgs {
     long long n;
     int ng;
     int tiles_per_block;  // ceil(rays_per_block / TILE)
+    int fixed_steps;      // k_ray_step_fixed: RK3 steps per launch (rays are independent: state stays in registers)
     long long rays_per_block;   // contiguous rays owned by a workgroup (multiple of 16: 128-B aligned
                           // starts); chosen so that the workgroups divide evenly over the CUs
     double dt;
@@ -871,8 +872,9 @@ __global__ void __launch_bounds__(BLOCK) k_deposit_only(const StageArgs a)
 
 // ------------------------------------------------------------------ K1f: fixed background, whole RK3 step in registers
 // The rhs hook that zeroes slots 9, 10 (BASELINE configs 1, 2): no inter-ray
-// dependency, so the three stages run back to back per ray and rr, mm (dens)
-// touch HBM once per step.
+// dependency, so the three stages run back to back per ray, and ALL the steps of
+// a call run in one launch: rr, mm (dens) touch HBM once per call, not per step
+// (same arithmetic in the same order: bit-identical to one launch per step).
 template <bool SAT, bool FVEC, bool DIRECT>
 __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
 {
@@ -916,6 +918,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
             const double f = FVEC ? ff[r] : a.f_uni;
             const double f2 = f * f;
             const double kh2 = kk[r] * kk[r] + ll[r] * ll[r];
+          for (int step = 0; step < a.fixed_steps; ++step) {
             const double rr_old = rr[r], mm_old = mm[r];
             double q_r = 0.0, q_m = 0.0, q_d = 0.0;
 #pragma unroll
@@ -966,6 +969,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
                 const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
                 if (maxd < dens[r] * pvf[r]) dens[r] = maxd;
             }
+          }
         }
         if (own) {
             store2(a.r.rr, i0, rr);
