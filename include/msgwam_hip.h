@@ -61,6 +61,8 @@ typedef struct {
     int32_t persist_steps;       /* RK3 steps covered by ONE launch in the last msgw_step call: persistent coupled kernel
                                     or fused fixed-background kernel (0 = one launch per RK stage)       */
     int32_t exchange;            /* 1: multi-rank steps use the in-kernel node-level flux exchange */
+    int32_t persist_resident_tiles; /* tiles per workgroup the last persistent launch kept in registers */
+    int32_t reserved_;
 } msgw_counters_t;
 
 /* ABI version of the loaded library (== MSGW_ABI_VERSION). */

@@ -136,6 +136,7 @@ struct msgw_ctx {
     // persistent RK3 kernel (single rank, coupled)
     int persist = 1;                 // 0 disables (MSGW_PERSIST=0 or after a time-out)
     int service = 1;                 // reducer workgroups beside the workers (MSGW_SERVICE=0: last arriver reduces)
+    int regtiles = 1;                // register-resident tiles in the persistent kernel (MSGW_REGTILES=0 disables)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
     unsigned int *pdone = nullptr;   // PDONE_WORDS: [0] ready, [1] status, [32..33] done2, [64] final rows, [96] rank rows, [128..] group tickets
     double *flux2 = nullptr;         // [2][ncols] final flux rows of the persistent kernel
@@ -531,23 +532,40 @@ size_t persist_lds_bytes(int ng)
     return stage_lds_bytes(ng) + sizeof(double) * (size_t)7 * (ng - 1) + 32;
 }
 
-template <bool SAT, bool FVEC, bool DIRECT>
+template <bool SAT, bool FVEC, bool DIRECT, int NRES>
 int launch_persist_t(msgw_ctx *c, PersistArgs &pa, bool *resident)
 {
-    auto k = k_rk3_persist<SAT, FVEC, DIRECT>;
+    auto k = k_rk3_persist<SAT, FVEC, DIRECT, NRES>;
     const size_t lds = persist_lds_bytes(c->ng);
     if (int rc = ensure_lds(c, k, lds)) return rc;
     int per_cu = 0;
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, BLOCK, lds));
-    pa.s.grp_size = (c->blocks + PERSIST_GROUPS - 1) / PERSIST_GROUPS;
-    pa.ngroups = (c->blocks + pa.s.grp_size - 1) / pa.s.grp_size;
-    // reducer workgroups (one per group) when they fit beside the workers, else the last arriver reduces
     const long long slots = (long long)per_cu * c->ncu;
-    pa.nservice = (c->service && c->blocks + pa.ngroups + 1 + (pa.xch ? 1 : 0) <= slots) ? pa.ngroups : 0;
+    int blocks = c->blocks;
+    if (NRES > 0) {
+        // own geometry: as many ray workgroups as fit beside 16 reducers, the column and the exchange
+        // workgroup at this kernel's occupancy (2 per CU); register-resident tiles only pay when they
+        // are a good part of a workgroup's tiles
+        const long long ntiles = (c->n + TILE - 1) / TILE;
+        const long long maxb = slots - (16 + 2);
+        if (maxb < 1) { *resident = false; return MSGW_OK; }
+        const long long tpb = std::max<long long>((ntiles + maxb - 1) / maxb, 1);
+        if (tpb > 3 * NRES) { *resident = false; return MSGW_OK; }
+        blocks = (int)((ntiles + tpb - 1) / tpb);
+        pa.s.tiles_per_block = (int)tpb;
+        pa.s.rays_per_block = tpb * TILE;
+        pa.nworkers = blocks;
+    }
+    const int max_groups = NRES > 0 ? 16 : PERSIST_GROUPS;
+    pa.s.grp_size = (blocks + max_groups - 1) / max_groups;
+    pa.ngroups = (blocks + pa.s.grp_size - 1) / pa.s.grp_size;
+    // reducer workgroups (one per group) + the column workgroup when they fit beside the ray workgroups,
+    // else the last arriver reduces
+    pa.nservice = (c->service && blocks + pa.ngroups + 1 + (pa.xch ? 1 : 0) <= slots) ? pa.ngroups : 0;
     pa.opts = pa.nservice ? 0u : PERSIST_OPT_PRIO;
     if (const char *e = std::getenv("MSGW_PRIO")) pa.opts = std::atoi(e) ? PERSIST_OPT_PRIO : 0u;
     // + reducer workgroups + the column workgroup + the exchange workgroup
-    const int grid = c->blocks + pa.nservice + (pa.nservice ? 1 : 0) + (pa.xch ? 1 : 0);
+    const int grid = blocks + pa.nservice + (pa.nservice ? 1 : 0) + (pa.xch ? 1 : 0);
     *resident = slots >= grid && grid <= 2048;                 // every workgroup co-resident
     if (!*resident) return MSGW_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -557,6 +575,7 @@ int launch_persist_t(msgw_ctx *c, PersistArgs &pa, bool *resident)
     }
     hipExtLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, c->stream, e0, e1, 0, pa);
     HIPCHK(c, hipGetLastError());
+    c->cnt.persist_resident_tiles = NRES;
     return MSGW_OK;
 }
 
@@ -606,9 +625,16 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     c->time_next = time_kernels;
     int rc = MSGW_OK;
     const bool fv = c->fvec;
-    if (mode == 1) rc = fv ? launch_persist_t<true, true, false>(c, pa, &resident) : launch_persist_t<true, false, false>(c, pa, &resident);
-    else if (mode == 2) rc = fv ? launch_persist_t<false, true, true>(c, pa, &resident) : launch_persist_t<false, false, true>(c, pa, &resident);
-    else rc = fv ? launch_persist_t<false, true, false>(c, pa, &resident) : launch_persist_t<false, false, false>(c, pa, &resident);
+    c->cnt.persist_resident_tiles = 0;
+    // first choice: register-resident tiles (plain variant; declines for ray counts where they do not pay)
+    if (mode == 0 && !fv && c->regtiles) rc = launch_persist_t<false, false, false, 2>(c, pa, &resident);
+    if (rc == MSGW_OK && !resident) {
+        const StageArgs sa0 = make_stage_args(c, dt, flags);
+        pa.s.tiles_per_block = sa0.tiles_per_block; pa.s.rays_per_block = sa0.rays_per_block; pa.nworkers = c->blocks;
+        if (mode == 1) rc = fv ? launch_persist_t<true, true, false, 0>(c, pa, &resident) : launch_persist_t<true, false, false, 0>(c, pa, &resident);
+        else if (mode == 2) rc = fv ? launch_persist_t<false, true, true, 0>(c, pa, &resident) : launch_persist_t<false, false, true, 0>(c, pa, &resident);
+        else rc = fv ? launch_persist_t<false, true, false, 0>(c, pa, &resident) : launch_persist_t<false, false, false, 0>(c, pa, &resident);
+    }
     c->time_next = false;
     if (rc) return rc;
     if (!resident) return MSGW_OK;                             // grid larger than residency: per-stage path
@@ -853,6 +879,7 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     c->cnt.nranks = 1;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
+    if (const char *e = std::getenv("MSGW_REGTILES")) c->regtiles = std::atoi(e) ? 1 : 0;
     *out = c;
     return MSGW_OK;
 }

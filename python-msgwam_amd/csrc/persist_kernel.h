@@ -460,9 +460,10 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgs p, const Per
     }
 }
 
-template <int STAGE, bool SAT, bool FVEC, bool DIRECT>
+template <int STAGE, bool SAT, bool FVEC, bool DIRECT, int NRES>
 __device__ __forceinline__ bool persist_stage(const PersistArgs p, const PersistLds L, unsigned int q,
-                                              long long start, long long end, int tid, int wave, int lane)
+                                              long long start, long long end, int tid, int wave, int lane,
+                                              TileRegs (&res)[NRES > 0 ? NRES : 1])
 {
     const StageArgs a = p.s;
     const int ncp = a.ng - 2;
@@ -476,7 +477,9 @@ __device__ __forceinline__ bool persist_stage(const PersistArgs p, const Persist
     // poll's result is there after one round trip while the tile's 11 loads are still in flight.
     unsigned int seen = 0;
     if (q > 0 && tid == 0) seen = __hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, start, tid, end);
+    // `start` is the first STREAMED ray (the NRES resident tiles before it never leave the registers); a
+    // workgroup may have no streamed tile at all (workgroup-uniform test, the arrays are padded by one tile only)
+    if (NRES == 0 || start < end) load_tile<STAGE, SAT, FVEC, true, DIRECT>(cur, a, start, tid, end);
     if (q > 0) {
         if (!persist_wait_seen(p, q, seen, L.flag, tid, p.ready)) return false;
         if (p.nservice) {                                      // the column workgroup has published this pass's table
@@ -493,15 +496,19 @@ __device__ __forceinline__ bool persist_stage(const PersistArgs p, const Persist
     __syncthreads();
     int wmin = INT_MAX, wmax = INT_MIN;
     const StageLds SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
-    process_tiles<STAGE, SAT, FVEC, true, DIRECT, 2, true>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax);
+    process_tiles<STAGE, SAT, FVEC, true, DIRECT, 2, true, NRES>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax, &res);
     PSTAMP(q, 2);
     persist_publish(p, L.rows, ncp, L.flag, tid, q + 1u);     // this pass produced state_{q+1}: publish F_{q+1}
     PSTAMP(q, 3);
     return true;
 }
 
-template <bool SAT, bool FVEC, bool DIRECT>
-__global__ void __launch_bounds__(BLOCK, 4) k_rk3_persist(const PersistArgs p)
+// NRES > 0: the first NRES tiles of every ray workgroup are RESIDENT IN REGISTERS for the whole launch
+// (loaded once, written back once): at 2 workgroups per CU a lane has 256 VGPRs, enough for two tiles'
+// state (9 arrays x 2 rays x 2 VGPRs each) beside the working set, and the HBM traffic of a pass drops by
+// NRES / tiles_per_block.  Same tile order, same arithmetic: the deposit order is still ray order.
+template <bool SAT, bool FVEC, bool DIRECT, int NRES = 0>
+__global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const PersistArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const StageArgs a = p.s;
@@ -567,14 +574,48 @@ __global__ void __launch_bounds__(BLOCK, 4) k_rk3_persist(const PersistArgs p)
         deposit_pass<FVEC, 2>(a, SL, start, end, tid, wave, lane);
         persist_publish(p, L.rows, ncp, L.flag, tid, 0u);
     }
+    // resident tiles: everything a stage may read (stage 2 of the DIRECT variant reads the most); lanes
+    // beyond the workgroup's rays hold inert values and are never deposited or stored
+    TileRegs res[NRES > 0 ? NRES : 1];
+    if constexpr (NRES > 0) {
+#pragma unroll
+        for (int i = 0; i < NRES; ++i) {
+            const long long base = start + (long long)i * TILE;
+            if (base < end) {                                  // workgroup-uniform
+                load_tile<2, SAT, FVEC, true, DIRECT>(res[i], a, base, tid, end);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {                  // cg_rr of the initial state (carried from then on)
+                    const double f = FVEC ? res[i].ff[r] : a.f_uni;
+                    double kh2, m2, vk2, om;
+                    dispersion(res[i].kk[r], res[i].ll[r], res[i].mm[r], f * f, a.bvf2, kh2, m2, vk2, om, res[i].cg[r]);
+                }
+            } else {
+                TileRegs z{};
+                z.mm[0] = z.mm[1] = 1.0; z.kk[0] = z.kk[1] = 1.0; z.drr[0] = z.drr[1] = 1.0; z.pvf[0] = z.pvf[1] = 1.0;
+                z.v0 = z.v1 = false;
+                res[i] = z;
+            }
+        }
+    }
+    const long long sstart = start + (long long)NRES * TILE;    // first streamed ray
     unsigned int q = 0;
     for (int step = 0; step < p.nsteps; ++step) {
-        if (!persist_stage<0, SAT, FVEC, DIRECT>(p, L, q, start, end, tid, wave, lane)) return;
+        if (!persist_stage<0, SAT, FVEC, DIRECT, NRES>(p, L, q, sstart, end, tid, wave, lane, res)) return;
         ++q;
-        if (!persist_stage<1, SAT, FVEC, DIRECT>(p, L, q, start, end, tid, wave, lane)) return;
+        if (!persist_stage<1, SAT, FVEC, DIRECT, NRES>(p, L, q, sstart, end, tid, wave, lane, res)) return;
         ++q;
-        if (!persist_stage<2, SAT, FVEC, DIRECT>(p, L, q, start, end, tid, wave, lane)) return;
+        if (!persist_stage<2, SAT, FVEC, DIRECT, NRES>(p, L, q, sstart, end, tid, wave, lane, res)) return;
         ++q;
+    }
+    if constexpr (NRES > 0) {                                  // write the resident tiles back
+#pragma unroll
+        for (int i = 0; i < NRES; ++i) {
+            if (res[i].v0) {
+                store2(a.r.rr, res[i].off, res[i].rr);
+                store2(a.r.mm, res[i].off, res[i].mm);
+                if (SAT || DIRECT) store2(a.r.dens, res[i].off, res[i].dens);
+            }
+        }
     }
     if (blockIdx.x != 0 || p.nservice) return;
     // (no column workgroup:) workgroup 0 applies the last update (column_q needs F_{q-1}) and writes the column back;

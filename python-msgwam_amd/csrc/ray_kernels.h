@@ -505,6 +505,7 @@ __device__ __forceinline__ double sat_cap(double sat_c, double rho_f, double omh
 struct TileRegs {
     double rr[2], mm[2], kk[2], ll[2], dens[2], drr[2], vol[2], ff[2], pvf[2];
     double qr[2], qm[2], qd[2], rr0[2], mm0[2];
+    double cg[2];         // resident tiles only: cg_rr of the current state (see tile_body.inc)
     unsigned int off;     // byte offset of this lane's ray pair in every SoA array
     bool v0, v1;
 };
@@ -561,10 +562,11 @@ struct StageLds {
 // deposit the state this stage has just PRODUCED, i.e. the next stage's wave_projection input.
 // Same values (cg_rr is re-evaluated from the same kk, ll, new mm the next stage will load), but the
 // flux of stage q+1 is then published one whole pass before it is needed.
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH, bool LAG = false>
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH, bool LAG = false, int NRES = 0>
 __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds L, TileRegs &cur,
                                               long long start, long long end, int tid, int wave,
-                                              int lane, int &wmin, int &wmax)
+                                              int lane, int &wmin, int &wmax,
+                                              TileRegs (*res)[NRES > 0 ? NRES : 1] = nullptr)
 {
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
     const double4 *s_sh = L.sh;
@@ -577,132 +579,32 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
     for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int h = 0; h < (NH > 0 ? NH : 1); ++h) acc[p][h] = 0.0;
-    for (int t = 0; t < a.tiles_per_block; ++t) {
+    // resident tiles first: they are the workgroup's first NRES tiles, so the deposit order is ray order
+    if constexpr (NRES > 0) {
+        static_assert(NRES == 0 || STAGE != 3, "the single-RHS probe has no resident tiles");
+#pragma unroll
+        for (int i = 0; i < NRES; ++i) {
+#define TB_T (*res)[i]
+#define TB_RESIDENT true
+#define TB_IDX i
+#include "tile_body.inc"
+#undef TB_T
+#undef TB_RESIDENT
+#undef TB_IDX
+        }
+    }
+    // streamed tiles: `start` is the first streamed ray, `cur` holds its tile (already loaded)
+    for (int t = 0; t < a.tiles_per_block - NRES; ++t) {
         const long long base = start + (long long)t * TILE;
         if (base >= end) break;                              // workgroup-uniform
-        const bool more = (t + 1 < a.tiles_per_block) && (base + TILE < end);
-        const unsigned int i0 = cur.off;                     // byte offset shared by all arrays
-        const bool v0 = cur.v0, v1 = cur.v1;
-        const bool valid[2] = {v0, v1};
-        double (&rr)[2] = cur.rr, (&mm)[2] = cur.mm, (&kk)[2] = cur.kk, (&ll)[2] = cur.ll;
-        double (&dens)[2] = cur.dens, (&drr)[2] = cur.drr, (&vol)[2] = cur.vol, (&ff)[2] = cur.ff;
-        double (&pvf)[2] = cur.pvf, (&qr)[2] = cur.qr, (&qm)[2] = cur.qm, (&qd)[2] = cur.qd;
-        double (&rr0)[2] = cur.rr0, (&mm0)[2] = cur.mm0;
-        if (DIRECT && STAGE == 0 && v0) {                    // keep the start-of-step rr, mm
-            store2(a.r.rr0, i0, rr);
-            store2(a.r.mm0, i0, mm);
-        }
-
-        double lo[2], up[2], pay[2][2], nrr[2], nmm[2], ndens[2];
-        int nlo[2], nup[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const double f = FVEC ? ff[r] : a.f_uni;
-            const double f2 = f * f;
-            double kh2, m2, vk2, om, cgr;
-            dispersion(kk[r], ll[r], mm[r], f2, a.bvf2, kh2, m2, vk2, om, cgr);   // :635-636
-            const double st_rr = .5 * (cgr + cgr);                                  // :640
-            const Bracket bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
-            const double4 sh = s_sh[bk.j];                                          // {dudz, slu, dvdz, slv}
-            const double gu = interp_eval(rr[r], bk, sh.x, sh.y);                   // :355
-            const double gv = interp_eval(rr[r], bk, sh.z, sh.w);                   // :356
-            const double gradient = kk[r] * gu + ll[r] * gv;                        // :517
-            // :519-520: cg_lambda = cg_phi = 0 with HPROP off; the reference's division of that
-            // zero by (RAD_EARTH + rr) only matters for rr == -RAD_EARTH and is not reproduced.
-            const double st_mm = (kk[r] * 0.0 + ll[r] * 0.0) - gradient;
-            double st_dens = 0.0;
-            if (SAT) {                                                              // :647-651 -> :561-615
-                const double rr_f = rr[r] + st_rr * a.dt;                           // :591
-                const double mm_f = mm[r] + st_mm * a.dt;                           // :593
-                const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
-                const double2 rh = s_rho2[br.j];                                   // {rhobar, slope}
-                const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);   // :595
-                const double omh = a.same_f ? om : sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);   // :597
-                const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);  // :601
-                if (maxd < dens[r] * pvf[r]) st_dens = (maxd - dens[r]) / a.dt;     // :604, :613
-            }
-            if (DEPOSIT && !LAG) {
-                lo[r] = rr[r] - .5 * drr[r];                                        // :655
-                up[r] = rr[r] + .5 * drr[r];
-#if defined(MSGW_ABLATE) && MSGW_ABLATE == 3
-                nlo[r] = (int)(lo[r] * a.inv_dzs); nup[r] = nlo[r] + 1;
-#else
-                deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, a.inv_dzs, a.mk_ok, nc - 2, nlo[r], nup[r]);
-#endif
-                // :148-149.  The reference evaluates cg_rr at .5*((mm-.5*dmm)+(mm+.5*dmm)), which
-                // equals mm to within 1 ulp; the stage's own cgr is reused here.
-                pay[0][r] = cgr * kk[r] * dens[r];
-                pay[1][r] = cgr * ll[r] * dens[r];
-            }
-            if (STAGE == 3) {
-                nrr[r] = st_rr; nmm[r] = st_mm; ndens[r] = st_dens;
-            } else {
-                double q_r, q_m, q_d = 0.0;
-                if (STAGE == 0) {                                                   // :693-694
-                    q_r = a.dt * st_rr; q_m = a.dt * st_mm;
-                    nrr[r] = rr[r] + div_const(q_r, 3.0, THIRD_RN, 1);
-                    nmm[r] = mm[r] + div_const(q_m, 3.0, THIRD_RN, 1);
-                    if (SAT) { q_d = a.dt * st_dens; ndens[r] = dens[r] + div_const(q_d, 3.0, THIRD_RN, 1); }
-                } else if (STAGE == 1) {                                            // :695-696
-                    q_r = a.dt * st_rr - RK_A1 * qr[r]; q_m = a.dt * st_mm - RK_A1 * qm[r];
-                    nrr[r] = rr[r] + RK_B1 * q_r; nmm[r] = mm[r] + RK_B1 * q_m;
-                    if (SAT) { q_d = a.dt * st_dens - RK_A1 * qd[r]; ndens[r] = dens[r] + RK_B1 * q_d; }
-                } else {                                                            // :697-698
-                    q_r = a.dt * st_rr - RK_A2 * qr[r]; q_m = a.dt * st_mm - RK_A2 * qm[r];
-                    nrr[r] = rr[r] + RK_B2 * q_r; nmm[r] = mm[r] + RK_B2 * q_m;
-                    if (SAT) { q_d = a.dt * st_dens - RK_A2 * qd[r]; ndens[r] = dens[r] + RK_B2 * q_d; }
-                }
-                qr[r] = q_r; qm[r] = q_m; qd[r] = q_d;
-                if (DIRECT && STAGE == 2) {                   // raytracer.py:182-188 -> :561-610
-                    const double d_in = SAT ? ndens[r] : dens[r];
-                    const double rr_st = (nrr[r] - rr0[r]) / a.sat_rr_div;          // raytracer.py:184
-                    const double mm_st = (nmm[r] - mm0[r]) / a.dt;                  // raytracer.py:187
-                    const double rr_f = rr0[r] + rr_st * a.dt;
-                    const double mm_f = mm0[r] + mm_st * a.dt;
-                    const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
-                    const double2 rh = s_rho2[br.j];                                   // {rhobar, slope}
-                    const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);   // :595
-                    const double m02 = mm0[r] * mm0[r];
-                    const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m02) / (kh2 + m02));   // :597 (old mm)
-                    const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
-                    ndens[r] = (maxd < d_in * pvf[r]) ? maxd : d_in;                // :604-608
-                }
-            }
-            if (DEPOSIT && LAG) {                             // deposit of the NEW state (next stage's :654-658)
-                const double dn = (SAT || (DIRECT && STAGE == 2)) ? ndens[r] : dens[r];
-                lo[r] = nrr[r] - .5 * drr[r];
-                up[r] = nrr[r] + .5 * drr[r];
-                deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, a.inv_dzs, a.mk_ok, nc - 2, nlo[r], nup[r]);
-                double kh2n, m2n, vk2n, omn, cgn;
-                dispersion(kk[r], ll[r], nmm[r], f2, a.bvf2, kh2n, m2n, vk2n, omn, cgn);
-                pay[0][r] = cgn * kk[r] * dn;
-                pay[1][r] = cgn * ll[r] * dn;
-            }
-        }
-
-#ifdef MSGW_STAMP
-        asm volatile("" :: "v"(nrr[0]), "v"(nmm[1]));
-        MSGW_STAMP_AT(2 + 2 * (t & 1));
-#endif
-        if (v0) {                                            // only the owner stores (pairs never straddle)
-            if (STAGE == 3) {
-                store2(a.r.q_rr, i0, nrr);
-                store2(a.r.q_mm, i0, nmm);
-                store2(a.r.q_dens, i0, ndens);
-            } else {
-                store2(a.r.rr, i0, nrr);
-                store2(a.r.mm, i0, nmm);
-                if (SAT || (DIRECT && STAGE == 2)) store2(a.r.dens, i0, ndens);
-                if (STAGE != 2) {
-                    store2(a.r.q_rr, i0, qr);
-                    store2(a.r.q_mm, i0, qm);
-                    if (SAT) store2(a.r.q_dens, i0, qd);
-                }
-            }
-        }
-        if (DEPOSIT)
-            deposit_tile<2, NH>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok,
-                                s_rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
+        const bool more = (t + 1 < a.tiles_per_block - NRES) && (base + TILE < end);
+#define TB_T cur
+#define TB_RESIDENT false
+#define TB_IDX t
+#include "tile_body.inc"
+#undef TB_T
+#undef TB_RESIDENT
+#undef TB_IDX
         MSGW_STAMP_AT(3 + 2 * (t & 1));
         if (more) load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, base + TILE, tid, end);
     }

@@ -36,7 +36,8 @@ class Counters(C.Structure):
                 ("ray_kernel_launches", C.c_int64), ("ray_steps_total", C.c_int64),
                 ("nray", C.c_int64), ("ngrid", C.c_int32), ("blocks", C.c_int32),
                 ("graph_steps", C.c_int32), ("nranks", C.c_int32), ("persist_steps", C.c_int32),
-                ("exchange", C.c_int32)]
+                ("exchange", C.c_int32),
+                ("persist_resident_tiles", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class MsgwError(RuntimeError):

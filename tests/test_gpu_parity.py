@@ -265,6 +265,37 @@ def test_full_size_config3_properties_and_subsample():
     p.close()
 
 
+def test_full_size_config2_fixed_background_1000_steps():
+    """BASELINE config 2 size (1e5 rays, fixed background, 1000 RK3 steps): every ray against the C
+    oracle (P2: rtol 1e-10), in ONE call (all steps fused in one launch) and in 10 calls of 100."""
+    from msgwam_amd.spectrum import gaussian_spectrum
+    n = 100_000
+    grid = np.linspace(0, 100e3, 101)
+    s0 = orc.Setup(grid)
+    sp = gaussian_spectrum(n, s0.grids, s0.rhobar, alpha=0.01)
+    s = orc.Setup(grid, dkk=sp["dkk"], dll=sp["dll"], rr_mm_area=sp["area"])
+    uu = orc.velocities_sine_homogeneous(s.grids, 4.0, 40e3, 10e3)
+    vv = np.zeros_like(uu)
+    s.set_pressure_gradient(uu, vv)
+    st = [sp[k] for k in STATE_KEYS[:9]] + [uu, vv]
+    want = COracle(s, fixed_background=True).step(120.0, 1000, st)
+    p = make_prop(s, st)
+    p.step(120.0, 1000, _capi.FIXED_BACKGROUND)
+    assert p.counters()["persist_steps"] == 1000
+    one = gpu_state(p, st)
+    p.close()
+    p = make_prop(s, st)
+    for _ in range(10):
+        p.step(120.0, 100, _capi.FIXED_BACKGROUND)
+    ten = gpu_state(p, st)
+    p.close()
+    for k, a, b in zip(STATE_KEYS, one, ten):
+        assert np.array_equal(a, b), f"1 call of 1000 steps differs from 10 calls of 100 in {k}"
+    for i, k in ((0, "dens"), (3, "rr"), (7, "mm")):
+        assert relerr(one[i], want[i]) <= 1e-10, (k, relerr(one[i], want[i]))
+    assert np.array_equal(one[9], st[9]) and np.array_equal(one[10], st[10])
+
+
 def test_tall_column_path_vs_c_oracle():
     """ngrid = 301 (> 130 levels): per-level sums stay in LDS, standalone column kernel per stage."""
     rng = np.random.default_rng(77)
