@@ -251,7 +251,8 @@ def main():
                                                   if c1.get("exchange") and persist_steps else
                                                   "by ncclAllReduce once per RK stage (lagged launch chain)"))
                        if (world > 1 or args.force_collective) else "single GPU",
-                       "graph_steps": c1["graph_steps"], "persist_steps": persist_steps, "blocks": c1["blocks"]},
+                       "graph_steps": c1["graph_steps"], "persist_steps": persist_steps, "blocks": c1["blocks"],
+                       "register_resident_tiles_per_workgroup": c1.get("persist_resident_tiles", 0)},
             "whole_job_hbm_frac": None if fused_note else value * bps / 1e9 / (HBM_PEAK_GBS * world),
             "state_finite": finite,
             "roofline": roofline,
