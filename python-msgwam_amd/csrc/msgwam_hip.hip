@@ -626,8 +626,12 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     int rc = MSGW_OK;
     const bool fv = c->fvec;
     c->cnt.persist_resident_tiles = 0;
-    // first choice: register-resident tiles (plain variant; declines for ray counts where they do not pay)
-    if (mode == 0 && !fv && c->regtiles) rc = launch_persist_t<false, false, false, 2>(c, pa, &resident);
+    // first choice: register-resident tiles (declines for ray counts where they do not pay)
+    if (c->regtiles) {
+        if (mode == 1) rc = fv ? launch_persist_t<true, true, false, 2>(c, pa, &resident) : launch_persist_t<true, false, false, 2>(c, pa, &resident);
+        else if (mode == 2) rc = fv ? launch_persist_t<false, true, true, 2>(c, pa, &resident) : launch_persist_t<false, false, true, 2>(c, pa, &resident);
+        else rc = fv ? launch_persist_t<false, true, false, 2>(c, pa, &resident) : launch_persist_t<false, false, false, 2>(c, pa, &resident);
+    }
     if (rc == MSGW_OK && !resident) {
         const StageArgs sa0 = make_stage_args(c, dt, flags);
         pa.s.tiles_per_block = sa0.tiles_per_block; pa.s.rays_per_block = sa0.rays_per_block; pa.nworkers = c->blocks;
