@@ -328,6 +328,15 @@ def gen_g4():
         if nt in rows:
             d.update(flat_state(f"s{nt}", [cur[k] for k in STATE_KEYS] + [cur_uu, cur_vv]))
             d[f"s{nt}_dens_prop"] = dens_prop
+            # the driver's conservation diagnostic on this stored row (raytracer.py:198-240): wave action
+            # on `grid` (var=2, :213) and vertical wave-action flux on `grids` (var=1, :227)
+            lo, up = cur["rr"] - .5 * cur["drr"], cur["rr"] + .5 * cur["drr"]
+            mlo, mup = cur["mm"] - .5 * cur["dmm"], cur["mm"] + .5 * cur["dmm"]
+            d[f"s{nt}_wa"] = lprop.wave_projection(cur["dens"], cur["lam"], cur["phi"], lo, up, cur["kk"], cur["ll"],
+                                                   mlo, mup, ic["dkk"], ic["dll"], cur["dmm"], grid, var=2)
+            d[f"s{nt}_flux_diag"] = lprop.wave_projection(cur["dens"], cur["lam"], cur["phi"], lo, up, cur["kk"],
+                                                          cur["ll"], mlo, mup, ic["dkk"], ic["dll"], cur["dmm"],
+                                                          grids, var=1)
     d["n_saturation_events"] = nsat
     save("g4_saturation_direct_driver", **d)
     print("   driver loop saturation events:", nsat)

@@ -119,5 +119,10 @@ def test_driver_matches_reference_loop(mode, nt, every):
         assert np.max(np.abs(H["int_uu"][n] - d[f"s{n}_uu"])) / scale <= 1e-10
     if mode == "dropin":
         assert relerr(H["int_dens_prop"][100], d["s100_dens_prop"]) <= 1e-10
-        # conservation diagnostic (raytracer.py:198-240): wave action is projected and finite
-        assert H["wa"].shape == (nt + 1, 100) and np.all(np.isfinite(H["wa"])) and H["wa"].max() > 0
+        # conservation diagnostic (raytracer.py:198-240) against the reference's own rows: wave action on
+        # `grid` (var=2) and vertical wave-action flux on `grids` (var=1), projected from the GPU states
+        assert H["wa"].shape == (nt + 1, 100) and H["flux_diag"].shape == (nt + 1, 99)
+        for n in (1, 10, 100):
+            for k in ("wa", "flux_diag"):
+                want = d[f"s{n}_{k}"]
+                assert np.max(np.abs(H[k][n] - want)) <= 1e-10 * np.max(np.abs(want)), (n, k)

@@ -160,3 +160,20 @@ def test_g5_spectrum_coupled():
     for n, st in got.items():
         for k, a in zip(STATE_KEYS, st):
             assert relerr(a, d[f"s{n}_{k}"]) <= 1e-12, (n, k)
+
+
+def test_driver_conservation_diagnostic_rows():
+    """raytracer.py:198-240 on stored rows of the driver run: the oracle's wave_projection var=2 (on grid)
+    and var=1 (on grids) reproduce the reference's wa / flux_diag rows bit for bit."""
+    d = load("g4_saturation_direct_driver")
+    grid = d["grid"]
+    grids = .5 * (grid[:-1] + grid[1:])
+    for n in (1, 10, 100, 710, 1000, 1440):
+        g = {k: d[f"s{n}_{k}"] for k in ("dens", "phi", "rr", "drr", "kk", "ll", "mm", "dmm")}
+        lo, up = g["rr"] - .5 * g["drr"], g["rr"] + .5 * g["drr"]
+        mlo, mup = g["mm"] - .5 * g["dmm"], g["mm"] + .5 * g["dmm"]
+        wa = orc.wave_projection(g["dens"], lo, up, g["kk"], g["ll"], mlo, mup, g["phi"], d["dkk"], d["dll"],
+                                 g["dmm"], grid, float(d["bvf"]), var=2)
+        fl = orc.wave_projection(g["dens"], lo, up, g["kk"], g["ll"], mlo, mup, g["phi"], d["dkk"], d["dll"],
+                                 g["dmm"], grids, float(d["bvf"]), var=1)
+        assert np.array_equal(wa, d[f"s{n}_wa"]) and np.array_equal(fl, d[f"s{n}_flux_diag"]), n
