@@ -102,6 +102,12 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1 only: run the multi-GPU path with a 1-rank communicator (diagnostic; "
                          "MSGW_EXCHANGE=0 selects the RCCL launch chain instead of the in-kernel exchange)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the N>1 launch (only carries the unique id, barriers and the "
+                         "max-over-ranks time; the flux exchange is the library's own)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="diagnostic: all ranks use GPU 0 (rehearsal of the N>1 path on a 1-GPU box; implies the "
+                         "exchange-only communicator because RCCL refuses two ranks on one device; use --backend gloo)")
     ap.add_argument("--kernel-events", choices=["separate", "same", "none"], default="separate",
                     help="where the per-launch HIP-event timing of the dominant kernel is taken")
     args = ap.parse_args()
@@ -122,11 +128,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
+        os.environ["MSGW_EXCHANGE_ONLY"] = "1"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     lprop, grid, grids, uu, vv = column(args.ngrid)
     flags = _capi.FIXED_BACKGROUND if args.workload == "fixed" else 0
@@ -170,7 +182,7 @@ def main():
         wall = time.perf_counter() - t0
         c1 = p.counters()
         if dist is not None:
-            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         kern_ms, launches = None, 0

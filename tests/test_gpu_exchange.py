@@ -101,3 +101,24 @@ def test_ranks_as_processes_sharing_the_gpu(tmp_path, nranks, n):
         got[i] = np.concatenate([o[k] for o in outs])
     got[9], got[10] = outs[0]["uu"], outs[0]["vv"]
     check_state(got, want, 1e-10, 1e-11, f"{nranks} ranks vs one")
+
+
+def test_bench_multi_rank_launch_rehearsal(tmp_path):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per process),
+    rehearsed on ONE GPU: --share-gpu puts both ranks on GPU 0 with the exchange-only communicator and
+    --backend gloo carries the unique id / barriers.  Checks the contract's JSON line of rank 0."""
+    import json
+    root = os.path.join(HERE, "..")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--backend", "gloo", "--share-gpu", "--rays-per-gpu", "60000"]
+    r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-3000:]                # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["rays_total"] == 120000 and d["state_finite"] is True
+    assert "inside the persistent kernel" in d["config"]["parallelism"]
+    assert d["roofline"]["kernel"] == "k_rk3_persist" and d["value"] > 0
