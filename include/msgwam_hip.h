@@ -46,6 +46,12 @@ typedef struct msgw_ctx msgw_ctx;
 #define MSGW_DIRECT_SAT         4u  /* the same with "/ dt"                                         */
 #define MSGW_NO_GRAPH           8u  /* launch kernels eagerly instead of replaying a hipGraph       */
 #define MSGW_TIME_KERNELS      16u  /* bracket every ray-stage kernel with HIP events (implies NO_GRAPH) */
+#define MSGW_RELAUNCH          32u  /* EXTENSION, not in the reference (BASELINE config 5): after every RK3 step
+                                       a ray whose volume has left the column (rr - drr/2 > grid[-1] or
+                                       rr + drr/2 < grid[0]) or whose dens fell below frac x its source value
+                                       (msgw_set_relaunch) is recycled to the (dens, rr, mm) it was uploaded with.
+                                       Comparisons with NaN are false.  Checked once per RK3 step, after the
+                                       direct saturation when that is on.  Runs in the per-stage kernels.  */
 
 /* counters filled by msgw_counters */
 typedef struct {
@@ -64,6 +70,9 @@ typedef struct {
     int32_t persist_resident_tiles; /* tiles per workgroup the last persistent launch kept in registers */
     int32_t reserved_;
 } msgw_counters_t;
+
+/* EXTENSION: the "broken ray" fraction of MSGW_RELAUNCH (default 1e-6; 0 disables that criterion). */
+int msgw_set_relaunch(msgw_ctx *ctx, double frac);
 
 /* ABI version of the loaded library (== MSGW_ABI_VERSION). */
 int msgw_abi_version(void);

@@ -291,3 +291,31 @@ def driver_step(setup, dt, state, loop=False, fixed_background=False,
             old[4], (new[4] - old[4]) / dt, new[5], new[6], old[7],
             (new[7] - old[7]) / dt, direct=True)
     return new, dens_prop
+
+
+# --------------------------------------------------------------------------
+# EXTENSION (not in the reference; SURVEY 8f rank 2 / BASELINE config 5): removal +
+# continuous source relaunch.  Parity UNPINNED: this function is the definition,
+# the GPU path (MSGW_RELAUNCH) must match it.
+# --------------------------------------------------------------------------
+def relaunch(setup, state, source, frac=1e-6):
+    """After a complete RK3 step (and after the direct saturation, when used) a ray
+    slot is recycled to its SOURCE values of (dens, rr, mm) -- the values it was
+    launched with -- when
+      * its volume has left the column:  rr - drr/2 > grid[-1]  or  rr + drr/2 < grid[0]
+        (such rays deposit nothing any more, lib/libprop.py:129-135), or
+      * it has broken:  dens < frac * dens_source  (the reference's saturation
+        collapses dens by ~12 orders of magnitude, lib/libprop.py:604-610).
+    Comparisons with NaN are false (a NaN ray is left alone).  Everything else
+    (drr, kk, ll, dmm, lam, phi, the column) is untouched.
+    `source` = (dens, rr, mm) arrays.  Returns (new state list, mask of recycled rays)."""
+    st = [np.asarray(s, dtype=np.float64) for s in state]
+    dens, rr, drr, mm = st[0], st[3], st[4], st[7]
+    sd, sr, sm = (np.asarray(a, dtype=np.float64) for a in source)
+    z_bot, z_top = setup.grid[0], setup.grid[-1]
+    with np.errstate(invalid="ignore"):
+        out = (rr - .5 * drr > z_top) | (rr + .5 * drr < z_bot) | (dens < frac * sd)
+    st[0] = np.where(out, sd, dens)
+    st[3] = np.where(out, sr, rr)
+    st[7] = np.where(out, sm, mm)
+    return st, out

@@ -101,7 +101,9 @@ struct msgw_ctx {
     std::vector<double *> ray_bufs;
     double *dens = nullptr, *rr = nullptr, *mm = nullptr, *drr = nullptr, *kk = nullptr, *ll = nullptr,
            *dmm = nullptr, *vol = nullptr, *fray = nullptr, *pvf = nullptr, *q_rr = nullptr,
-           *q_mm = nullptr, *q_dens = nullptr, *rr0 = nullptr, *mm0 = nullptr;
+           *q_mm = nullptr, *q_dens = nullptr, *rr0 = nullptr, *mm0 = nullptr,
+           *src_dens = nullptr, *src_rr = nullptr, *src_mm = nullptr;   // MSGW_RELAUNCH: values at upload
+    double relaunch_frac = 1e-6;
     bool fvec = false;
     double f_uni = 0;
 
@@ -112,7 +114,7 @@ struct msgw_ctx {
            *slu = nullptr, *slv = nullptr, *slrho = nullptr, *flux = nullptr, *out_du = nullptr,
            *out_dv = nullptr, *out_flux = nullptr;
     double *alt_uu = nullptr, *alt_vv = nullptr, *alt_q_uu = nullptr, *alt_q_vv = nullptr;   // 2nd column set
-    double dzg = 0, dzs = 0, xg0 = 0, gs0 = 0, xg_last = 0, gs_last = 0;
+    double dzg = 0, dzs = 0, xg0 = 0, gs0 = 0, xg_last = 0, gs_last = 0, z_bot = 0, z_top = 0;
 
     // launch geometry + per-workgroup flux rows
     int blocks_per_cu = 4;
@@ -375,7 +377,9 @@ StageArgs make_stage_args(msgw_ctx *c, double dt, unsigned flags)
     a.dzs = c->dzs;
     a.mk_ok = markstein_ok(c->dzs);
     a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
-                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0};
+                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0, c->src_dens, c->src_rr, c->src_mm};
+    a.relaunch = (flags & MSGW_RELAUNCH) ? 1 : 0;
+    a.z_bot = c->z_bot; a.z_top = c->z_top; a.relaunch_frac = c->relaunch_frac;
     a.c = ColPtrs{c->grid + 1, c->dudz, c->dvdz, c->slu, c->slv, c->grids, c->rhobar, c->slrho};
     a.partial = c->partial;
     a.ranges = c->ranges;
@@ -437,16 +441,19 @@ int launch_ray_kernel(msgw_ctx *c, K k, size_t lds, const StageArgs &a)
     return MSGW_OK;
 }
 
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
+// RL: the MSGW_RELAUNCH extension (stage 2 only; a compile-time variant so that the default kernels carry
+// none of its registers)
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool RL = false>
 int launch_stage_t(msgw_ctx *c, const StageArgs &a)
 {
+    constexpr bool GR = DEPOSIT && STAGE != 3;
     if (c->ng - 2 > 128)   // tall columns: per-level sums stay in LDS (NH = 0)
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 0>, stage_lds_bytes(c->ng), a);
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 0, false, false, RL>, stage_lds_bytes(c->ng), a);
     if (c->lagchain && DEPOSIT && STAGE != 3)   // lagged chain: deposit of the produced state, group rows by parity
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, (DEPOSIT && STAGE != 3), (DEPOSIT && STAGE != 3)>, stage_lds_bytes(c->ng), a);
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, GR, GR, RL>, stage_lds_bytes(c->ng), a);
     if (c->groupred && DEPOSIT && STAGE != 3)   // fused chain: first-level flux reduction inside the kernel
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, (DEPOSIT && STAGE != 3)>, stage_lds_bytes(c->ng), a);
-    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2>, stage_lds_bytes(c->ng), a);
+        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, GR, false, RL>, stage_lds_bytes(c->ng), a);
+    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, false, false, RL>, stage_lds_bytes(c->ng), a);
 }
 
 // mode: 0 plain, 1 online saturation, 2 direct (driver) saturation
@@ -454,6 +461,14 @@ template <int STAGE>
 int launch_stage(msgw_ctx *c, const StageArgs &a, int mode)
 {
     const bool fv = c->fvec;
+    if (STAGE == 2 && a.relaunch) {                            // extension: recycle rays after the step's last stage
+        if (mode == 1) return fv ? launch_stage_t<2, true, true, true, false, true>(c, a)
+                                 : launch_stage_t<2, true, false, true, false, true>(c, a);
+        if (mode == 2) return fv ? launch_stage_t<2, false, true, true, true, true>(c, a)
+                                 : launch_stage_t<2, false, false, true, true, true>(c, a);
+        return fv ? launch_stage_t<2, false, true, true, false, true>(c, a)
+                  : launch_stage_t<2, false, false, true, false, true>(c, a);
+    }
     if (mode == 1) return fv ? launch_stage_t<STAGE, true, true, true, false>(c, a)
                              : launch_stage_t<STAGE, true, false, true, false>(c, a);
     if (mode == 2 && STAGE != 1) return fv ? launch_stage_t<STAGE, false, true, true, true>(c, a)
@@ -586,8 +601,8 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     *used = false;
     const bool can_fuse = (2 * (c->ng - 2) <= BLOCK) && (c->ng - 1 <= BLOCK);
     const bool multi = c->nranks > 1 || c->force_coll;
-    if (!c->persist || !can_fuse || (multi && !c->xch_ok) || (flags & MSGW_FIXED_BACKGROUND) || count <= 0)
-        return MSGW_OK;
+    if (!c->persist || !can_fuse || (multi && !c->xch_ok) || (flags & (MSGW_FIXED_BACKGROUND | MSGW_RELAUNCH)) || count <= 0)
+        return MSGW_OK;                                        // (the relaunch extension lives in the per-stage kernels)
     const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
     PersistArgs pa{};
     pa.s = make_stage_args(c, dt, flags);
@@ -855,7 +870,7 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
     double **rp[] = {&c->dens, &c->rr, &c->mm, &c->drr, &c->kk, &c->ll, &c->dmm, &c->vol, &c->fray,
-                     &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0};
+                     &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0, &c->src_dens, &c->src_rr, &c->src_mm};
     const size_t padded = (((size_t)nray_cap + TILE - 1) / TILE + 1) * TILE;   // whole tiles + one: unconditional vector access
     for (double **p : rp) {
         CR(hipMalloc(p, padded * sizeof(double)));
@@ -951,6 +966,7 @@ int msgw_set_column(msgw_ctx *c, const double *grid, const double *grids, const 
     c->dzs = grids[1] - grids[0];                    // the same on grids     (:123 with G = grids)
     c->xg0 = grid[1];
     c->gs0 = grids[0];
+    c->z_bot = grid[0]; c->z_top = grid[ng - 1];     // MSGW_RELAUNCH: the column's extent
     c->xg_last = grid[ng - 2];                       // last point of grid[1:-1]
     c->gs_last = grids[nc - 1];
     if (!(c->dzg > 0) || !(c->dzs > 0)) return fail(c, MSGW_ERR_ARG, "grid must be increasing");
@@ -977,6 +993,10 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
         {c->dens, dens}, {c->rr, rr}, {c->drr, drr}, {c->kk, kk}, {c->ll, ll}, {c->mm, mm},
         {c->dmm, dmm}, {c->fray, fray}, {c->q_rr, dkk}, {c->q_mm, dll}, {c->q_dens, area}};
     for (auto &x : cp) HIPCHK(c, hipMemcpyAsync(x.d, x.h, B, hipMemcpyHostToDevice, c->stream));
+    // the source a recycled slot returns to (MSGW_RELAUNCH) is the state at upload
+    HIPCHK(c, hipMemcpyAsync(c->src_dens, c->dens, B, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->src_rr, c->rr, B, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->src_mm, c->mm, B, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (long long)n,
                        c->q_rr, c->q_mm, c->q_dens, c->drr, c->dmm, c->vol, c->pvf);
     HIPCHK(c, hipGetLastError());
@@ -986,7 +1006,7 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
         struct { double *p; double v; } pad[] = {
             {c->dens, 0.0}, {c->rr, 0.0}, {c->mm, 1.0}, {c->drr, 1.0}, {c->kk, 1.0}, {c->ll, 0.0},
             {c->dmm, 0.0}, {c->vol, 0.0}, {c->fray, 0.0}, {c->pvf, 1.0}, {c->q_rr, 0.0}, {c->q_mm, 0.0},
-            {c->q_dens, 0.0}, {c->rr0, 0.0}, {c->mm0, 1.0}};
+            {c->q_dens, 0.0}, {c->rr0, 0.0}, {c->mm0, 1.0}, {c->src_dens, 0.0}, {c->src_rr, 0.0}, {c->src_mm, 1.0}};
         for (auto &x : pad)
             hipLaunchKernelGGL(k_fill_range, dim3((unsigned)((n_pad - n + 255) / 256)), dim3(256), 0, c->stream,
                                x.p, (long long)n, n_pad, x.v);
@@ -1005,6 +1025,15 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
     c->have_rays = true;
     c->cnt.nray = n;
     c->cnt.blocks = c->blocks;
+    drop_graph(c);
+    return MSGW_OK;
+}
+
+int msgw_set_relaunch(msgw_ctx *c, double frac)
+{
+    if (!c) return MSGW_ERR_ARG;
+    if (!(frac >= 0.0) || !(frac < 1.0)) return fail(c, MSGW_ERR_ARG, "relaunch fraction must be in [0, 1)");
+    c->relaunch_frac = frac;
     drop_graph(c);
     return MSGW_OK;
 }
@@ -1163,7 +1192,7 @@ int msgw_project(msgw_ctx *c, int var, const double *G, int nG, double *out)
     a.bvf2 = std::pow(c->bvf, 2.0); a.f_uni = c->f_uni; a.dz = G[1] - G[0];
     a.cdz = 1.0 / a.dz; a.mk_ok = markstein_ok(a.dz);
     a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
-                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0};
+                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0, c->src_dens, c->src_rr, c->src_mm};
     return run_projection(c, a, false, var == 0 ? 2 : 1, G, nG, out);
 }
 

@@ -27,6 +27,7 @@ struct RayPtrs {
     const double *pvf;                             // dkk*dll*(rr_mm_area/drr) (:594, :599)
     double *q_rr, *q_mm, *q_dens;                  // low-storage RK registers
     double *rr0, *mm0;                             // start-of-step copies (direct saturation)
+    const double *src_dens, *src_rr, *src_mm;      // EXTENSION: source values for MSGW_RELAUNCH
 };
 
 struct ColPtrs {
@@ -41,6 +42,8 @@ struct StageArgs {
     int ng;
     int tiles_per_block;  // ceil(rays_per_block / TILE)
     int fixed_steps;      // k_ray_step_fixed: RK3 steps per launch (rays are independent: state stays in registers)
+    int relaunch;         // EXTENSION (MSGW_RELAUNCH): recycle rays that left the column or broke, after stage 2
+    double z_bot, z_top, relaunch_frac;
     long long rays_per_block;   // contiguous rays owned by a workgroup (multiple of 16: 128-B aligned
                           // starts); chosen so that the workgroups divide evenly over the CUs
     double dt;
@@ -562,7 +565,8 @@ struct StageLds {
 // deposit the state this stage has just PRODUCED, i.e. the next stage's wave_projection input.
 // Same values (cg_rr is re-evaluated from the same kk, ll, new mm the next stage will load), but the
 // flux of stage q+1 is then published one whole pass before it is needed.
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH, bool LAG = false, int NRES = 0>
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH, bool LAG = false, int NRES = 0,
+          bool RELAUNCH = false>
 __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds L, TileRegs &cur,
                                               long long start, long long end, int tid, int wave,
                                               int lane, int &wmin, int &wmax,
@@ -658,7 +662,7 @@ __device__ __forceinline__ void deposit_pass(const StageArgs a, const StageLds L
 // carries s_waitcnt vmcnt(0), which drains the prefetch.  The other resident workgroups cover
 // a workgroup's load latency instead.)
 template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH = 2, bool GROUPRED = false,
-          bool LAG = false>
+          bool LAG = false, bool RELAUNCH = false>
 __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -742,7 +746,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
 
     int wmin = INT_MAX, wmax = INT_MIN;
     const StageLds L{s_sh, s_rho2, s_xg, s_gs, s_rows};
-    process_tiles<STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH, LAG>(a, L, cur, start, end, tid, wave, lane, wmin, wmax);
+    process_tiles<STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH, LAG, 0, RELAUNCH>(a, L, cur, start, end, tid, wave, lane, wmin, wmax);
     if (DEPOSIT) {
         if (GROUPRED) flush_rows_group<2>(s_rows, ncp, s_rng, lds /* interp tables are dead by now */, tid, a);
         else flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
@@ -815,6 +819,12 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
         load2(a.r.ll, i0, ll);
         if (FVEC) load2(a.r.fray, i0, ff);
         if (NEED_RHO) { load2(a.r.dens, i0, dens); load2(a.r.pvf, i0, pvf); }
+        double sd[2] = {0.0, 0.0}, sr[2] = {0.0, 0.0}, sm[2] = {0.0, 0.0}, drr[2] = {0.0, 0.0};
+        if (a.relaunch) {                                     // workgroup-uniform
+            load2(a.r.src_dens, i0, sd); load2(a.r.src_rr, i0, sr); load2(a.r.src_mm, i0, sm);
+            load2(a.r.drr, i0, drr);
+            if (!NEED_RHO) load2(a.r.dens, i0, dens);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const double f = FVEC ? ff[r] : a.f_uni;
@@ -871,12 +881,17 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
                 const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
                 if (maxd < dens[r] * pvf[r]) dens[r] = maxd;
             }
+            if (a.relaunch) {                                 // EXTENSION MSGW_RELAUNCH (include/msgwam_hip.h)
+                const bool out = (rr[r] - .5 * drr[r] > a.z_top) || (rr[r] + .5 * drr[r] < a.z_bot) ||
+                                 (dens[r] < a.relaunch_frac * sd[r]);
+                if (out) { dens[r] = sd[r]; rr[r] = sr[r]; mm[r] = sm[r]; }
+            }
           }
         }
         if (own) {
             store2(a.r.rr, i0, rr);
             store2(a.r.mm, i0, mm);
-            if (NEED_RHO) store2(a.r.dens, i0, dens);
+            if (NEED_RHO || a.relaunch) store2(a.r.dens, i0, dens);
         }
     }
 }

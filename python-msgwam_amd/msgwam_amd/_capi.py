@@ -20,12 +20,13 @@ DIRECT_SAT_QUIRK = 2
 DIRECT_SAT = 4
 NO_GRAPH = 8
 TIME_KERNELS = 16
+RELAUNCH = 32           # extension, see include/msgwam_hip.h
 
 EXPORTS = [
     "msgw_abi_version", "msgw_last_error", "msgw_create", "msgw_destroy", "msgw_set_config",
     "msgw_set_column", "msgw_upload_rays", "msgw_step", "msgw_rhs", "msgw_project",
     "msgw_project_arrays", "msgw_saturation", "msgw_download_rays", "msgw_download_column",
-    "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters",
+    "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters", "msgw_set_relaunch",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -75,6 +76,7 @@ def load_library():
     lib.msgw_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.msgw_set_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.msgw_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+    lib.msgw_set_relaunch.argtypes = [C.c_void_p, C.c_double]
     if lib.msgw_abi_version() != 1:
         raise MsgwError("libmsgwam_hip.so has an unexpected ABI version")
     _lib = lib
@@ -151,6 +153,10 @@ class Propagator:
 
     def set_tuning(self, blocks_per_cu=4, graph_steps=0):
         self._chk(self.lib.msgw_set_tuning(self.ctx, int(blocks_per_cu), int(graph_steps)), "msgw_set_tuning")
+
+    def set_relaunch(self, frac=1e-6):
+        """EXTENSION (not in the reference): broken-ray fraction of the RELAUNCH flag."""
+        self._chk(self.lib.msgw_set_relaunch(self.ctx, float(frac)), "msgw_set_relaunch")
 
     # -- hot path --------------------------------------------------------------
     def step(self, dt, nsteps=1, flags=0):

@@ -42,7 +42,7 @@ def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "python-msgwam_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".inc")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("ORACLE", "").lower() or f == "README.md", \
                     f"{f} mentions the oracle: the product path must not depend on it"
