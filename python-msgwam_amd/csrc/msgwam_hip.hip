@@ -102,7 +102,8 @@ struct msgw_ctx {
     double *dens = nullptr, *rr = nullptr, *mm = nullptr, *drr = nullptr, *kk = nullptr, *ll = nullptr,
            *dmm = nullptr, *vol = nullptr, *fray = nullptr, *pvf = nullptr, *q_rr = nullptr,
            *q_mm = nullptr, *q_dens = nullptr, *rr0 = nullptr, *mm0 = nullptr,
-           *src_dens = nullptr, *src_rr = nullptr, *src_mm = nullptr;   // MSGW_RELAUNCH: values at upload
+           *src_dens = nullptr, *src_rr = nullptr, *src_mm = nullptr,   // MSGW_RELAUNCH: values at upload
+           *cgbuf = nullptr;                                            // cg_rr carried between passes (persistent kernel)
     double relaunch_frac = 1e-6;
     bool fvec = false;
     double f_uni = 0;
@@ -377,7 +378,7 @@ StageArgs make_stage_args(msgw_ctx *c, double dt, unsigned flags)
     a.dzs = c->dzs;
     a.mk_ok = markstein_ok(c->dzs);
     a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
-                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0, c->src_dens, c->src_rr, c->src_mm};
+                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0, c->src_dens, c->src_rr, c->src_mm, c->cgbuf};
     a.relaunch = (flags & MSGW_RELAUNCH) ? 1 : 0;
     a.z_bot = c->z_bot; a.z_top = c->z_top; a.relaunch_frac = c->relaunch_frac;
     a.c = ColPtrs{c->grid + 1, c->dudz, c->dvdz, c->slu, c->slv, c->grids, c->rhobar, c->slrho};
@@ -870,7 +871,7 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
     double **rp[] = {&c->dens, &c->rr, &c->mm, &c->drr, &c->kk, &c->ll, &c->dmm, &c->vol, &c->fray,
-                     &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0, &c->src_dens, &c->src_rr, &c->src_mm};
+                     &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0, &c->src_dens, &c->src_rr, &c->src_mm, &c->cgbuf};
     const size_t padded = (((size_t)nray_cap + TILE - 1) / TILE + 1) * TILE;   // whole tiles + one: unconditional vector access
     for (double **p : rp) {
         CR(hipMalloc(p, padded * sizeof(double)));
@@ -1192,7 +1193,7 @@ int msgw_project(msgw_ctx *c, int var, const double *G, int nG, double *out)
     a.bvf2 = std::pow(c->bvf, 2.0); a.f_uni = c->f_uni; a.dz = G[1] - G[0];
     a.cdz = 1.0 / a.dz; a.mk_ok = markstein_ok(a.dz);
     a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
-                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0, c->src_dens, c->src_rr, c->src_mm};
+                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0, c->src_dens, c->src_rr, c->src_mm, c->cgbuf};
     return run_projection(c, a, false, var == 0 ? 2 : 1, G, nG, out);
 }
 

@@ -28,6 +28,8 @@ struct RayPtrs {
     double *q_rr, *q_mm, *q_dens;                  // low-storage RK registers
     double *rr0, *mm0;                             // start-of-step copies (direct saturation)
     const double *src_dens, *src_rr, *src_mm;      // EXTENSION: source values for MSGW_RELAUNCH
+    double *cg;                                    // cg_rr of the current state (persistent kernel with resident
+                                                   // tiles: carried from the pass that produced the state)
 };
 
 struct ColPtrs {
@@ -513,7 +515,7 @@ struct TileRegs {
     bool v0, v1;
 };
 
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT>
+template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool CGMEM = false>
 __device__ __forceinline__ void load_tile(TileRegs &t, const StageArgs a, long long base, int tid,
                                           long long end)
 {
@@ -544,6 +546,7 @@ __device__ __forceinline__ void load_tile(TileRegs &t, const StageArgs a, long l
         load2(a.r.rr0, t.off, t.rr0);
         load2(a.r.mm0, t.off, t.mm0);
     }
+    if (CGMEM) load2(a.r.cg, t.off, t.cg);
 }
 
 // LDS views shared by the stage kernels
@@ -578,6 +581,9 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
     const double *s_xg = L.xg, *s_gs = L.gs;
     double *s_rows = L.rows;
     (void)s_rho2; (void)ng;
+    // with resident tiles the kernel is FP64-VALU bound, not HBM bound: streamed tiles then carry cg_rr of
+    // their state through memory (8 B store + 8 B load per ray-stage) instead of re-evaluating it
+    constexpr bool CGMEM = NRES > 0 && LAG && DEPOSIT && !SAT && !DIRECT;
     double acc[2][NH > 0 ? NH : 1];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -610,16 +616,16 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
 #undef TB_RESIDENT
 #undef TB_IDX
         MSGW_STAMP_AT(3 + 2 * (t & 1));
-        if (more) load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, base + TILE, tid, end);
+        if (more) load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT, CGMEM>(cur, a, base + TILE, tid, end);
     }
     if (DEPOSIT) flush_acc<2, NH>(s_rows + wave * 2 * ncp, ncp, lane, acc);
 }
 
 // Deposit-only pass over this workgroup's rays (no stores): wave_projection(var=0) of the CURRENT
 // state into the per-wave LDS rows.  Seeds the lagged-deposit pipeline of the persistent kernel.
-template <bool FVEC, int NH>
+template <bool FVEC, int NH, bool CGSTORE = false>
 __device__ __forceinline__ void deposit_pass(const StageArgs a, const StageLds L, long long start, long long end,
-                                             int tid, int wave, int lane)
+                                             int tid, int wave, int lane, long long cg_from = 0)
 {
     const int nc = a.ng - 1, ncp = a.ng - 2;
     int wmin = INT_MAX, wmax = INT_MIN;
@@ -638,19 +644,21 @@ __device__ __forceinline__ void deposit_pass(const StageArgs a, const StageLds L
         load2(a.r.rr, off, rr); load2(a.r.mm, off, mm); load2(a.r.kk, off, kk); load2(a.r.ll, off, ll);
         load2(a.r.dens, off, dens); load2(a.r.drr, off, drr); load2(a.r.vol, off, vol);
         if (FVEC) load2(a.r.fray, off, ff);
-        double lo[2], up[2], pay[2][2];
+        double lo[2], up[2], pay[2][2], cg2[2];
         int nlo[2], nup[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const double f = FVEC ? ff[r] : a.f_uni;
             double kh2, m2, vk2, om, cgr;
             dispersion(kk[r], ll[r], mm[r], f * f, a.bvf2, kh2, m2, vk2, om, cgr);
+            cg2[r] = cgr;
             lo[r] = rr[r] - .5 * drr[r];
             up[r] = rr[r] + .5 * drr[r];
             deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, a.inv_dzs, a.mk_ok, nc - 2, nlo[r], nup[r]);
             pay[0][r] = cgr * kk[r] * dens[r];
             pay[1][r] = cgr * ll[r] * dens[r];
         }
+        if (CGSTORE && valid[0] && base >= cg_from) store2(a.r.cg, off, cg2);   // streamed tiles of the persistent kernel
         deposit_tile<2, NH>(lo, up, nlo, nup, vol, pay, L.gs, a.dzs, a.inv_dzs, a.mk_ok,
                             L.rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
     }
