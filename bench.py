@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="diagnostic: all ranks use GPU 0 (rehearsal of the N>1 path on a 1-GPU box; implies the "
                          "exchange-only communicator because RCCL refuses two ranks on one device; use --backend gloo)")
-    ap.add_argument("--kernel-events", choices=["separate", "same", "none"], default="separate",
+    ap.add_argument("--kernel-events", choices=["separate", "same", "none"], default="same",
                     help="where the per-launch HIP-event timing of the dominant kernel is taken")
     args = ap.parse_args()
 
