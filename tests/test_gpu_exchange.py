@@ -108,9 +108,13 @@ def test_bench_multi_rank_launch_rehearsal(tmp_path):
     rehearsed on ONE GPU: --share-gpu puts both ranks on GPU 0 with the exchange-only communicator and
     --backend gloo carries the unique id / barriers.  Checks the contract's JSON line of rank 0."""
     import json
+    import socket
+    with socket.socket() as sk:                        # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     root = os.path.join(HERE, "..")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
            "--warmup", "2", "--backend", "gloo", "--share-gpu", "--rays-per-gpu", "60000"]
     r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
     out = r.stdout.decode(errors="replace")
