@@ -207,7 +207,7 @@ def main():
         v = big["n_total"] * max(args.steps // 4, 20) / big["wall"]
         extra = {"rays_per_gpu": big["n_total"], "value": v,
                  "whole_job_hbm_frac": v * BYTES_PER_RAY_STEP["coupled"] / 1e9 / HBM_PEAK_GBS,
-                 "note": "same workload at 4x the rays: the fixed per-stage synchronisation cost amortises"}
+                 "note": "same workload at 4x the rays"}
 
     if rank == 0:
         value = n_total * args.steps / wall

@@ -560,13 +560,14 @@ int launch_persist_t(msgw_ctx *c, PersistArgs &pa, bool *resident)
     int blocks = c->blocks;
     if (NRES > 0) {
         // own geometry: as many ray workgroups as fit beside 16 reducers, the column and the exchange
-        // workgroup at this kernel's occupancy (2 per CU); register-resident tiles only pay when they
-        // are a good part of a workgroup's tiles
+        // workgroup at this kernel's occupancy (2 per CU)
         const long long ntiles = (c->n + TILE - 1) / TILE;
         const long long maxb = slots - (16 + 2);
         if (maxb < 1) { *resident = false; return MSGW_OK; }
         const long long tpb = std::max<long long>((ntiles + maxb - 1) / maxb, 1);
-        if (tpb > 3 * NRES) { *resident = false; return MSGW_OK; }
+        // measured with 2 resident tiles: +10 % at 2e6 rays (8 tiles per workgroup), +3 % at 4e6 and 8e6 (16, 32),
+        // -10 % at 16e6 (64), where 4 workgroups per CU with all rays streamed are better
+        if (tpb > 16 * NRES) { *resident = false; return MSGW_OK; }
         blocks = (int)((ntiles + tpb - 1) / tpb);
         pa.s.tiles_per_block = (int)tpb;
         pa.s.rays_per_block = tpb * TILE;
