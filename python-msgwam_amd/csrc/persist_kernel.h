@@ -246,14 +246,12 @@ __device__ __forceinline__ void persist_reduce_group(const PersistArgs p, int g,
     __syncthreads();
 }
 
-// Third level: add the group sums (group order) into ONE final row, so that every workgroup reads
-// 2*(ng-2) values instead of ngroups times that; then announce it.
-__device__ __forceinline__ void persist_reduce_final(const PersistArgs p, unsigned int f, int ncols, int tid)
+// Third level: the sum of the group sums of flux f, in group order (thread `tid` < ncols: its column).
+__device__ __forceinline__ double persist_sum_groups(const PersistArgs p, unsigned int f, int ncols, int tid)
 {
-    const unsigned int par = f & 1u;
     double tot = 0.0;
     if (tid < ncols) {
-        const double *src = p.grp_rows2 + (size_t)par * PERSIST_GROUPS * ncols + tid;
+        const double *src = p.grp_rows2 + (size_t)(f & 1u) * PERSIST_GROUPS * ncols + tid;
         for (int r = 0; r < p.ngroups; r += 32) {
             double v[32];
 #pragma unroll
@@ -262,6 +260,15 @@ __device__ __forceinline__ void persist_reduce_final(const PersistArgs p, unsign
             for (int u = 0; u < 32; ++u) tot = tot + ((r + u < p.ngroups) ? v[u] : 0.0);
         }
     }
+    return tot;
+}
+
+// Without reducer workgroups: the last arriver of the flux's last group forms ONE final row (so that every
+// workgroup reads 2*(ng-2) values instead of ngroups times that) and announces it.
+__device__ __forceinline__ void persist_reduce_final(const PersistArgs p, unsigned int f, int ncols, int tid)
+{
+    const unsigned int par = f & 1u;
+    const double tot = persist_sum_groups(p, f, ncols, tid);
     // several ranks: this is only the rank's row; the exchange workgroup turns it into the final one
     double *dst = p.xch ? p.flux2 + 2 * ncols : p.flux2;
     if (tid < ncols) st_agent(dst + (size_t)par * ncols + tid, tot);
@@ -269,8 +276,7 @@ __device__ __forceinline__ void persist_reduce_final(const PersistArgs p, unsign
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for flux f+2
-        unsigned int *cnt = p.xch ? p.ready + PD_LOCAL : (p.nservice ? p.ready + PD_ROW : p.ready);
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(p.xch ? p.ready + PD_LOCAL : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -327,8 +333,7 @@ __device__ __forceinline__ void persist_publish(const PersistArgs p, const doubl
 }
 
 // Reducer workgroup of group g (owns no rays; p.nservice of them run beside the workers): for every
-// flux of the launch wait until the group's rows have all arrived, add them, and -- the reducer that
-// completes a flux -- add the group sums into the final row.  This takes ~6.5 us of serial L2 round
+// flux of the launch wait until the group's rows have all arrived and add them.  This takes ~6.5 us of serial L2 round
 // trips per pass off the LAST ARRIVER, which is the workgroup everybody else is waiting for
 // (tools/persist_timeline.py).  Each reducer polls its own ticket on its own cache line.
 __device__ __forceinline__ void persist_service(const PersistArgs p, int g, int *s_flag, int tid)
@@ -357,15 +362,25 @@ __device__ __forceinline__ void persist_service(const PersistArgs p, int g, int 
         __syncthreads();
         if (!s_flag[par]) return;
         persist_reduce_group(p, g, f, ncols, tid);
-        if (tid == 0) {
+        if (tid == 0) {                                       // the group sums are added by the column (one rank)
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for flux f+2
-            const unsigned int t2 = __hip_atomic_fetch_add(p.done2 + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            s_flag[2 + par] = (t2 == (unsigned int)p.ngroups - 1u) ? 1 : 0;
+            __hip_atomic_fetch_add(p.done2 + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // or exchange workgroup
         }
-        __syncthreads();
-        if (s_flag[2 + par]) persist_reduce_final(p, f, ncols, tid);
     }
+}
+
+// Column / exchange workgroup: wait until all group sums of flux f are there, add them (registers),
+// re-arm the counter.  Returns false after a time-out.
+__device__ __forceinline__ bool persist_take_groups(const PersistArgs p, unsigned int f, int ncols, int *s_flag,
+                                                    int tid, double &tot)
+{
+    const unsigned int par = f & 1u;
+    if (!persist_wait(p, (unsigned int)p.ngroups, s_flag, tid, p.done2 + par)) return false;
+    tot = persist_sum_groups(p, f, ncols, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the rows are in registers ...
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... re-arm for flux f+2
+    return true;
 }
 
 // The exchange workgroup (several ranks only; owns no rays): for every flux of the launch, wait for
@@ -378,8 +393,13 @@ __device__ __forceinline__ void persist_exchange(const PersistArgs p, int *s_fla
     const double *flux_local = p.flux2 + 2 * ncols;
     for (unsigned int f = 0; f < nflux; ++f) {
         const unsigned int par = f & 1u;
-        if (!persist_wait(p, f + 1u, s_flag + par, tid, p.ready + PD_LOCAL)) return;
-        const double mine = (tid < ncols) ? ld_agent(flux_local + (size_t)par * ncols + tid) : 0.0;
+        double mine = 0.0;
+        if (p.nservice) {                                      // add the reducers' group sums: the rank's row
+            if (!persist_take_groups(p, f, ncols, s_flag + par, tid, mine)) return;
+        } else {                                               // the last arriver has formed the rank's row
+            if (!persist_wait(p, f + 1u, s_flag + par, tid, p.ready + PD_LOCAL)) return;
+            if (tid < ncols) mine = ld_agent(flux_local + (size_t)par * ncols + tid);
+        }
         double tot = 0.0;
         if (!xch_allsum(x.nranks, x.rank, x.stride, x.rows, x.flags, x.seq + f + 1ull, p.status, x.timeout_ticks,
                         ncols, tid, s_flag + 2 + par, mine, tot))
@@ -399,15 +419,17 @@ struct PersistLds {
     int *flag;
 };
 
-// column_q = RK stage `pstage` of column_{q-1} with the final row of flux F_{q-1}
+// column_q = RK stage `pstage` of column_{q-1} with the final row of flux F_{q-1}; `have` = this thread's
+// value of the row (column `tid`) when the caller holds it in registers, else it is loaded from flux2
 __device__ __forceinline__ void persist_column(const PersistArgs p, const PersistLds L, unsigned int q,
-                                               int pstage, int tid)
+                                               int pstage, int tid, bool in_regs = false, double have = 0.0)
 {
     const StageArgs a = p.s;
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2, ncols = 2 * ncp;
     if (tid < ncols) {
         const int pp = tid / ncp, c = tid - pp * ncp;
-        L.F[pp * ng + 1 + c] = ld_agent(p.flux2 + (size_t)((q - 1) & 1) * ncols + tid);   // pm_flux[:, 1:-1] (:654)
+        L.F[pp * ng + 1 + c] = in_regs ? have                  // pm_flux[:, 1:-1] (:654)
+                                       : ld_agent(p.flux2 + (size_t)((q - 1) & 1) * ncols + tid);
     }
     __syncthreads();
     column_flux_ends(tid, ng, L.F);
@@ -439,9 +461,17 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgs p, const Per
 {
     const int ng = p.s.ng, ni = ng - 2, nc = ng - 1;
     const unsigned int nflux = 3u * (unsigned int)p.nsteps;      // the flux of the final state is unused
+    const int ncols = 2 * (ng - 2);
     for (unsigned int f = 0; f < nflux; ++f) {
-        if (!persist_wait(p, f + 1u, L.flag, tid, p.ready + PD_ROW)) return;
-        persist_column(p, L, f + 1u, (int)(f % 3u), tid);       // pass q = f+1 is RK stage q % 3, column stage (q+2) % 3
+        // pass q = f+1 is RK stage q % 3, column stage (q+2) % 3 = f % 3
+        if (p.xch) {                                           // several ranks: the exchange workgroup's final row
+            if (!persist_wait(p, f + 1u, L.flag, tid, p.ready + PD_ROW)) return;
+            persist_column(p, L, f + 1u, (int)(f % 3u), tid);
+        } else {                                               // one rank: add the reducers' group sums right here
+            double tot = 0.0;
+            if (!persist_take_groups(p, f, ncols, L.flag, tid, tot)) return;
+            persist_column(p, L, f + 1u, (int)(f % 3u), tid, true, tot);
+        }
         double *tab = p.shtab + (size_t)(f & 1u) * 4 * ni;
         const double *src = reinterpret_cast<const double *>(L.sh);
         for (int i = tid; i < 4 * ni; i += BLOCK) st_agent(tab + i, src[i]);
