@@ -362,8 +362,50 @@ def gen_g5():
     save("g5_spectrum_coupled", **d)
 
 
+# ---------------------------------------------------------------- G6
+def gen_g6():
+    """HPROP_GLOBAL = True (libprop's own default): lam, phi, kk, ll evolve too."""
+    rng = np.random.default_rng(20240606)
+    dt = 120.0
+    for tag, sat in (("sat0", False), ("sat1", True)):
+        grid, grids, uu, vv = configure(phi0=np.deg2rad(30.0), kappa=1.0, saturate_online=sat)
+        vv = 0.5 * uu[::-1].copy()
+        lprop.set_pressure_gradient(uu, vv)
+        lprop.HPROP_GLOBAL = True
+        ic = random_rays(rng, 257, grids, np.deg2rad(30.0), amp_scale=1.0)
+        ic["phi"] = rng.uniform(np.deg2rad(-70.0), np.deg2rad(70.0), 257)      # rays at scattered latitudes
+        ic["lam"] = rng.uniform(0.0, 2 * np.pi, 257)
+        st = pack(ic, uu, vv)
+        out = lprop.rhs_default(dt, st)
+        d = {}
+        d.update(flat_state("in", st))
+        d.update(flat_state("out", out))
+        d.update(dkk=ic["dkk"], dll=ic["dll"], area=ic["area"], pg=lprop.pressure_gradient.copy(),
+                 rhobar=lprop.rhobar.copy(), grid=grid, dt=dt, phi0=np.deg2rad(30.0), kappa=1.0, bvf=0.01,
+                 saturate_online=int(sat))
+        save(f"g6_hprop_rhs_{tag}", **d)
+    # RK3 with horizontal propagation, coupled, driver-like amplitudes
+    grid, grids, uu, vv = configure(phi0=np.deg2rad(30.0))
+    vv = 0.5 * uu[::-1].copy()
+    lprop.set_pressure_gradient(uu, vv)
+    lprop.HPROP_GLOBAL = True
+    ic = driver_ic(60, grids, alpha=0.01, phi0=np.deg2rad(30.0))
+    ic["phi"] = np.deg2rad(30.0) + np.linspace(-0.2, 0.2, 60)
+    ic["kk"] = ic["kk"] * np.linspace(0.5, 1.5, 60)
+    ic["ll"] = ic["kk"][::-1] * 0.7 + 1e-5
+    st = pack(ic, uu, vv)
+    d = dict(grid=grid, dt=dt, phi0=np.deg2rad(30.0), kappa=1.0, bvf=0.01, saturate_online=0,
+             dkk=ic["dkk"], dll=ic["dll"], area=ic["area"], pg=lprop.pressure_gradient.copy(),
+             rhobar=lprop.rhobar.copy())
+    d.update(flat_state("in", st))
+    for n, s_ in run_steps(st, dt, (1, 5, 20, 100)).items():
+        d.update(flat_state(f"s{n}", s_))
+    save("g6_hprop_rk3_coupled", **d)
+    lprop.HPROP_GLOBAL = False
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     np.seterr(all="ignore")
     for w in which:
         globals()["gen_" + w]()

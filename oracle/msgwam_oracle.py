@@ -38,7 +38,7 @@ class Setup:
 
     def __init__(self, grid, bvf=0.01, phi0=0.0, kappa=1.0, saturate_online=False,
                  hh=8500.0, rhobar0=1.2, boussinesq=False, dkk=None, dll=None,
-                 rr_mm_area=None):
+                 rr_mm_area=None, hprop=False):
         self.grid = np.asarray(grid, dtype=np.float64)
         self.grids = .5 * (self.grid[:-1] + self.grid[1:])       # raytracer.py:75
         self.bvf = bvf
@@ -51,6 +51,7 @@ class Setup:
         self.dkk = dkk
         self.dll = dll
         self.rr_mm_area = rr_mm_area
+        self.hprop = hprop                                       # lib/libprop.py:5 HPROP_GLOBAL
         # lib/libprop.py:47-62 set_hydrostatics
         if boussinesq:
             self.rhobar = rhobar0 * np.ones(self.grids.shape)
@@ -203,7 +204,7 @@ def saturation(setup, dt, dens, rr_center, rr_center_st, drr, drr_st, kk, ll,
 # a-2 / a-6  right-hand side  (HPROP_GLOBAL = False branch, scalar bvf)
 # --------------------------------------------------------------------------
 def rhs(setup, dt, state, loop=False, fixed_background=False, return_flux=False, flux_reduce=None):
-    """lib/libprop.py:618-676 with HPROP_GLOBAL=False (raytracer.py:38).
+    """lib/libprop.py:618-676; HPROP_GLOBAL=False (raytracer.py:38) unless setup.hprop.
 
     state = [dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv].
     `fixed_background=True` is the rhs-hook variant of BASELINE config 1/2:
@@ -216,16 +217,36 @@ def rhs(setup, dt, state, loop=False, fixed_background=False, return_flux=False,
     cgr_up = cg_rr(kk, ll, mm, phi, bvf)                 # :635 (rr unused)
     cgr_down = cg_rr(kk, ll, mm, phi, bvf)               # :636
     zeros = np.zeros(np.shape(kk))
-    # :638-639  cg_lambda/cg_phi return zeros when HPROP is off
-    dlam_st = zeros / (RAD_EARTH + rr) / np.cos(phi)
-    dphi_st = zeros / (RAD_EARTH + rr)
-    drr_st = .5 * (cgr_down + cgr_up)                    # :640
-    ddrr_st = cgr_up - cgr_down                          # :641
-    dkk_st = np.zeros(np.shape(kk))                      # :470-471
-    dll_st = np.zeros(np.shape(kk))                      # :498-499
     du_dz_ray, dv_dz_ray = shear_at_rays(setup, rr, uu, vv)
     gradient = (kk * du_dz_ray + ll * dv_dz_ray)         # :517
-    dmm_st = (kk * zeros + ll * zeros) / (RAD_EARTH + rr) - gradient   # :519-520
+    if setup.hprop:
+        # HPROP_GLOBAL = True (lib/libprop.py:5): horizontal propagation on the sphere
+        om = omega(kk, ll, mm, phi, bvf)
+        vk_square = kk ** 2 + ll ** 2 + mm ** 2
+        uu_ray = np.interp(rr, setup.grids, uu)          # :399, :357
+        vv_ray = np.interp(rr, setup.grids, vv)          # :422, :358
+        cg_lam = kk / om / vk_square * (bvf ** 2 - om ** 2) + uu_ray     # :404
+        cg_ph = ll / om / vk_square * (bvf ** 2 - om ** 2) + vv_ray      # :428
+        cgr = cg_rr(kk, ll, mm, phi, bvf)
+        dlam_st = cg_lam / (RAD_EARTH + rr) / np.cos(phi)                # :638
+        dphi_st = cg_ph / (RAD_EARTH + rr)                               # :639
+        grad_k = (kk * zeros + ll * zeros) / (RAD_EARTH + rr) / np.cos(phi)   # :463-464 (no horizontal wind gradients)
+        dkk_st = kk / (RAD_EARTH + rr) * (np.tan(phi) * cg_ph - cgr) - grad_k   # :467-468
+        grad_l = (kk * zeros + ll * zeros) / (RAD_EARTH + rr)            # :487
+        df2_dphi = 8 * ROT_EARTH ** 2 * np.sin(phi) * np.cos(phi) * 1    # :489
+        dll_st = - (ll * cgr + kk * np.tan(phi) * cg_lam
+                    + mm ** 2 / 2 / om / (kk ** 2 + ll ** 2 + mm ** 2) * df2_dphi) / (RAD_EARTH + rr) \
+            - grad_l                                                     # :492-496
+        dmm_st = (kk * cg_lam + ll * cg_ph) / (RAD_EARTH + rr) - gradient   # :519-520
+    else:
+        # :638-639  cg_lambda/cg_phi return zeros when HPROP is off
+        dlam_st = zeros / (RAD_EARTH + rr) / np.cos(phi)
+        dphi_st = zeros / (RAD_EARTH + rr)
+        dkk_st = np.zeros(np.shape(kk))                  # :470-471
+        dll_st = np.zeros(np.shape(kk))                  # :498-499
+        dmm_st = (kk * zeros + ll * zeros) / (RAD_EARTH + rr) - gradient   # :519-520
+    drr_st = .5 * (cgr_down + cgr_up)                    # :640
+    ddrr_st = cgr_up - cgr_down                          # :641
     ddmm_st = dmm / drr * ddrr_st                        # :645
     dens_st = setup.saturate_online * saturation(        # :647-651
         setup, dt, dens, rr, drr_st, drr, ddrr_st, kk, ll, mm, dmm_st)

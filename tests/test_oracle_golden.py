@@ -177,3 +177,28 @@ def test_driver_conservation_diagnostic_rows():
         fl = orc.wave_projection(g["dens"], lo, up, g["kk"], g["ll"], mlo, mup, g["phi"], d["dkk"], d["dll"],
                                  g["dmm"], grids, float(d["bvf"]), var=1)
         assert np.array_equal(wa, d[f"s{n}_wa"]) and np.array_equal(fl, d[f"s{n}_flux_diag"]), n
+
+
+@pytest.mark.parametrize("name", ["g6_hprop_rhs_sat0", "g6_hprop_rhs_sat1"])
+def test_hprop_rhs_bit_exact(name):
+    """HPROP_GLOBAL = True (lib/libprop.py:404-405, :428-429, :465-469, :489-497, :519-520, :638-639): the
+    oracle's spherical branch reproduces the reference's 11 tendencies bit for bit."""
+    d = load(name)
+    s = setup_from(d)
+    s.hprop = True
+    out = orc.rhs(s, float(d["dt"]), state_from(d, "in"))
+    for i, k in enumerate(STATE_KEYS):
+        assert np.array_equal(out[i], d[f"out_{k}"], equal_nan=True), k
+
+
+def test_hprop_rk3_rows_bit_exact():
+    d = load("g6_hprop_rk3_coupled")
+    s = setup_from(d)
+    s.hprop = True
+    st = state_from(d, "in")
+    for n in range(1, 21):
+        st = orc.rk3(s, float(d["dt"]), st)
+        if n in (1, 5, 20):
+            for i, k in enumerate(STATE_KEYS):
+                assert np.array_equal(st[i], d[f"s{n}_{k}"], equal_nan=True), (n, k)
+    assert not np.array_equal(st[2], d["in_phi"]) and not np.array_equal(st[5], d["in_kk"])   # they really evolve
