@@ -71,6 +71,11 @@ typedef struct {
     int32_t reserved_;
 } msgw_counters_t;
 
+/* HPROP on: slots 1 and 2 (lam, phi) of the rays uploaded by the last msgw_upload_rays (same n). */
+int msgw_upload_hprop(msgw_ctx *ctx, int64_t n, const double *lam, const double *phi);
+/* HPROP on: lam, phi, kk, ll (any pointer may be NULL); tendencies != 0: their tendencies left by msgw_rhs. */
+int msgw_download_hprop(msgw_ctx *ctx, int64_t n, int tendencies, double *lam, double *phi, double *kk, double *ll);
+
 /* EXTENSION: the "broken ray" fraction of MSGW_RELAUNCH (default 1e-6; 0 disables that criterion). */
 int msgw_set_relaunch(msgw_ctx *ctx, double frac);
 
@@ -88,7 +93,9 @@ int msgw_destroy(msgw_ctx *ctx);
 /* model_config scalars read by the hot path (lib/libprop.py:380, :534, :582-584,
  * :633) and the module flag HPROP_GLOBAL (lib/libprop.py:5, raytracer.py:38).
  * f0 = 2*ROT_EARTH*sin(phi0) is computed by the caller in numpy so that sin()
- * is bit-identical to the reference.  hprop != 0 -> MSGW_ERR_UNSUP. */
+ * is bit-identical to the reference.  hprop != 0 (lib/libprop.py:5 HPROP_GLOBAL = True, libprop's own
+ * default; raytracer.py:38 switches it off): lam, phi, kk, ll evolve as well; the steps then run in a
+ * kernel of their own (one launch per RK stage) and need msgw_upload_hprop after msgw_upload_rays. */
 int msgw_set_config(msgw_ctx *ctx, double bvf, double f0, double kappa,
                     int saturate_online, int hprop);
 

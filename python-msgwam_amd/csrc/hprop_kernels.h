@@ -1,0 +1,162 @@
+// HPROP_GLOBAL = True (lib/libprop.py:5): horizontal propagation on the sphere.  lam, phi, kk, ll evolve as
+// well as rr, mm (dens); drr, dmm stay frozen (ddrr_st = cgr_up - cgr_down = 0 exactly, :641, :645).
+// raytracer.py switches this off (:38) and the tuned kernels serve that case; this is the reference's own
+// default mode, kept in a kernel of its own so that it costs the tuned ones nothing: one launch per RK stage
+// (deposit of the stage's INPUT state, per-workgroup flux rows -> k_column), 2 rays per lane, plain loads.
+// Operation order follows the reference line by line; sin/cos/tan come from the device math library, so
+// per-ray results agree with numpy to a few ulp, not bit for bit (rtol 1e-10 is asserted).
+#pragma once
+#include "ray_kernels.h"
+
+namespace msgw {
+
+struct HpropArgs {
+    StageArgs s;                                   // rays (kk, ll are written here), constants, tables, flux rows
+    double *lam, *phi, *kk, *ll;                   // evolving slots 1, 2, 5, 6
+    double *q_lam, *q_phi, *q_kk, *q_ll;           // their low-storage RK registers (STAGE 3: the tendencies)
+    const double *uu, *vv;                         // the column on grids, for uu_ray / vv_ray (:357-358)
+    double rad_earth, two_rot, df2c;               // RAD_EARTH, 2*ROT_EARTH, 8*ROT_EARTH**2 (:489)
+};
+
+template <int STAGE, bool SAT>
+__global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const StageArgs a = h.s;
+    const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
+    double4 *s_sh = reinterpret_cast<double4 *>(lds);                     // [ni] {dudz, slope, dvdz, slope}
+    double2 *s_rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);          // [nc] {rhobar, slope}
+    double *s_xg = lds + 4 * ni + 2 * nc;                                  // [ni] grid[1:-1]
+    double *s_gs = s_xg + ni;                                              // [nc] grids
+    double4 *s_uv = reinterpret_cast<double4 *>(s_gs + nc + ((ni + nc) & 1));   // [nc] {uu, slope, vv, slope} (16-B aligned)
+    double *s_rows = reinterpret_cast<double *>(s_uv + nc);                // [WAVES][2][ncp]
+    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * 2 * ncp);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    for (int i = tid; i < ni; i += BLOCK) {
+        s_xg[i] = a.c.xg[i];
+        const bool in = i < ni - 1;
+        s_sh[i] = make_double4(a.c.dudz[i], in ? a.c.slu[i] : 0.0, a.c.dvdz[i], in ? a.c.slv[i] : 0.0);
+    }
+    for (int i = tid; i < nc; i += BLOCK) {
+        s_gs[i] = a.c.grids[i];
+        s_rho2[i] = make_double2(a.c.rhobar[i], (i < nc - 1) ? a.c.slrho[i] : 0.0);
+        const bool in = i < nc - 1;                            // np.interp slope (f[j+1]-f[j])/(x[j+1]-x[j])
+        const double dx = in ? a.c.grids[i + 1] - a.c.grids[i] : 1.0;
+        s_uv[i] = make_double4(h.uu[i], in ? (h.uu[i + 1] - h.uu[i]) / dx : 0.0,
+                               h.vv[i], in ? (h.vv[i + 1] - h.vv[i]) / dx : 0.0);
+    }
+    for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) s_rows[i] = 0.0;
+    __syncthreads();
+
+    const long long start = (long long)blockIdx.x * a.rays_per_block;
+    const long long end = min(a.n, start + a.rays_per_block);
+    int wmin = INT_MAX, wmax = INT_MIN;
+    double acc[2][1] = {{0.0}, {0.0}};
+    for (int t = 0; t < a.tiles_per_block; ++t) {
+        const long long base = start + (long long)t * TILE;
+        if (base >= end) break;
+        const long long e0 = base + 2 * tid;
+        const unsigned int i0 = (unsigned int)(e0 * 8);
+        const bool valid[2] = {e0 < end, e0 + 1 < end};
+        double dens[2], lam[2], phi[2], rr[2], drr[2], kk[2], ll[2], mm[2], vol[2], pvf[2] = {1.0, 1.0};
+        double qd[2] = {0, 0}, qla[2] = {0, 0}, qph[2] = {0, 0}, qr[2] = {0, 0}, qk[2] = {0, 0}, ql[2] = {0, 0},
+               qm[2] = {0, 0};
+        load2(a.r.dens, i0, dens); load2(h.lam, i0, lam); load2(h.phi, i0, phi); load2(a.r.rr, i0, rr);
+        load2(a.r.drr, i0, drr); load2(h.kk, i0, kk); load2(h.ll, i0, ll); load2(a.r.mm, i0, mm);
+        load2(a.r.vol, i0, vol);
+        if (SAT) load2(a.r.pvf, i0, pvf);
+        if (STAGE == 1 || STAGE == 2) {
+            load2(h.q_lam, i0, qla); load2(h.q_phi, i0, qph); load2(a.r.q_rr, i0, qr); load2(h.q_kk, i0, qk);
+            load2(h.q_ll, i0, ql); load2(a.r.q_mm, i0, qm);
+            if (SAT) load2(a.r.q_dens, i0, qd);
+        }
+        double lo[2], up[2], pay[2][2];
+        double n_dens[2], n_lam[2], n_phi[2], n_rr[2], n_kk[2], n_ll[2], n_mm[2];
+        int nlo[2], nup[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const double sinp = sin(phi[r]), cosp = cos(phi[r]), tanp = tan(phi[r]);
+            const double f = h.two_rot * sinp;                                      // :382
+            const double f2 = f * f;
+            double kh2, m2, vk2, om, cgr;
+            dispersion(kk[r], ll[r], mm[r], f2, a.bvf2, kh2, m2, vk2, om, cgr);   // :369-383, :434-448
+            const Bracket bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
+            const double4 sh = s_sh[bk.j];
+            const double gu = interp_eval(rr[r], bk, sh.x, sh.y);                   // du/dz at the ray (:355)
+            const double gv = interp_eval(rr[r], bk, sh.z, sh.w);                   // dv/dz at the ray (:356)
+            const Bracket bu = interp_locate(rr[r], s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+            const double4 uv = s_uv[bu.j];
+            const double uu_ray = interp_eval(rr[r], bu, uv.x, uv.y);               // :357
+            const double vv_ray = interp_eval(rr[r], bu, uv.z, uv.w);               // :358
+            const double disp = a.bvf2 - om * om;
+            const double cg_lam = kk[r] / om / vk2 * disp + uu_ray;                 // :404
+            const double cg_ph = ll[r] / om / vk2 * disp + vv_ray;                  // :428
+            const double R = h.rad_earth + rr[r];
+            const double st_lam = cg_lam / R / cosp;                                // :638
+            const double st_phi = cg_ph / R;                                        // :639
+            const double st_rr = .5 * (cgr + cgr);                                  // :640
+            const double zero_grad = kk[r] * 0.0 + ll[r] * 0.0;                     // no horizontal wind gradients (:360-364)
+            const double st_kk = kk[r] / R * (tanp * cg_ph - cgr) - zero_grad / R / cosp;      // :463-468
+            const double df2 = h.df2c * sinp * cosp * 1;                            // :489
+            const double st_ll = -(ll[r] * cgr + kk[r] * tanp * cg_lam + m2 / 2 / om / vk2 * df2) / R
+                                 - zero_grad / R;                                   // :487-496
+            const double st_mm = (kk[r] * cg_lam + ll[r] * cg_ph) / R - (kk[r] * gu + ll[r] * gv);   // :517-520
+            double st_dens = 0.0;
+            if (SAT) {                                                              // :647-651 -> :561-615
+                const double rr_f = rr[r] + st_rr * a.dt;
+                const double mm_f = mm[r] + st_mm * a.dt;
+                const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+                const double2 rh = s_rho2[br.j];
+                const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);
+                const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);        // omega(kk, ll, mm, phi0) (:597)
+                const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
+                if (maxd < dens[r] * pvf[r]) st_dens = (maxd - dens[r]) / a.dt;
+            }
+            lo[r] = rr[r] - .5 * drr[r];                                            // :655
+            up[r] = rr[r] + .5 * drr[r];
+            deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, a.inv_dzs, a.mk_ok, nc - 2, nlo[r], nup[r]);
+            pay[0][r] = cgr * kk[r] * dens[r];                                      // :148-149
+            pay[1][r] = cgr * ll[r] * dens[r];
+            if (STAGE == 3) {
+                n_dens[r] = st_dens; n_lam[r] = st_lam; n_phi[r] = st_phi; n_rr[r] = st_rr;
+                n_kk[r] = st_kk; n_ll[r] = st_ll; n_mm[r] = st_mm;
+            } else {
+                const double st[7] = {st_dens, st_lam, st_phi, st_rr, st_kk, st_ll, st_mm};
+                const double y[7] = {dens[r], lam[r], phi[r], rr[r], kk[r], ll[r], mm[r]};
+                double q[7] = {qd[r], qla[r], qph[r], qr[r], qk[r], ql[r], qm[r]};
+                double yn[7];
+#pragma unroll
+                for (int v = 0; v < 7; ++v) {                                       // :693-698
+                    if (STAGE == 0) { q[v] = a.dt * st[v]; yn[v] = y[v] + div_const(q[v], 3.0, THIRD_RN, 1); }
+                    else if (STAGE == 1) { q[v] = a.dt * st[v] - RK_A1 * q[v]; yn[v] = y[v] + RK_B1 * q[v]; }
+                    else { q[v] = a.dt * st[v] - RK_A2 * q[v]; yn[v] = y[v] + RK_B2 * q[v]; }
+                }
+                n_dens[r] = SAT ? yn[0] : dens[r];
+                n_lam[r] = yn[1]; n_phi[r] = yn[2]; n_rr[r] = yn[3]; n_kk[r] = yn[4]; n_ll[r] = yn[5]; n_mm[r] = yn[6];
+                qd[r] = q[0]; qla[r] = q[1]; qph[r] = q[2]; qr[r] = q[3]; qk[r] = q[4]; ql[r] = q[5]; qm[r] = q[6];
+            }
+        }
+        if (valid[0]) {                                        // only the owner stores (pairs never straddle)
+            if (STAGE == 3) {
+                store2(a.r.q_dens, i0, n_dens); store2(h.q_lam, i0, n_lam); store2(h.q_phi, i0, n_phi);
+                store2(a.r.q_rr, i0, n_rr); store2(h.q_kk, i0, n_kk); store2(h.q_ll, i0, n_ll);
+                store2(a.r.q_mm, i0, n_mm);
+            } else {
+                if (SAT) store2(a.r.dens, i0, n_dens);
+                store2(h.lam, i0, n_lam); store2(h.phi, i0, n_phi); store2(a.r.rr, i0, n_rr);
+                store2(h.kk, i0, n_kk); store2(h.ll, i0, n_ll); store2(a.r.mm, i0, n_mm);
+                if (STAGE != 2) {
+                    if (SAT) store2(a.r.q_dens, i0, qd);
+                    store2(h.q_lam, i0, qla); store2(h.q_phi, i0, qph); store2(a.r.q_rr, i0, qr);
+                    store2(h.q_kk, i0, qk); store2(h.q_ll, i0, ql); store2(a.r.q_mm, i0, qm);
+                }
+            }
+        }
+        deposit_tile<2, 0>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
+                           ncp, lane, wmin, wmax, acc);
+    }
+    flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
+}
+
+}   // namespace msgw

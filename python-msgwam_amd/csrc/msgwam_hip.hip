@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "column_kernels.h"
+#include "hprop_kernels.h"
 #include "persist_kernel.h"
 #include "ray_kernels.h"
 
@@ -105,6 +106,10 @@ struct msgw_ctx {
            *src_dens = nullptr, *src_rr = nullptr, *src_mm = nullptr,   // MSGW_RELAUNCH: values at upload
            *cgbuf = nullptr;                                            // cg_rr carried between passes (persistent kernel)
     double relaunch_frac = 1e-6;
+    // HPROP_GLOBAL = True (horizontal propagation): lam, phi and their RK registers, registers of kk, ll
+    int hprop = 0;
+    bool have_hprop = false;
+    double *lam = nullptr, *phi = nullptr, *q_lam = nullptr, *q_phi = nullptr, *q_kk = nullptr, *q_ll = nullptr;
     bool fvec = false;
     double f_uni = 0;
 
@@ -833,6 +838,56 @@ int ready(msgw_ctx *c)
     if (!c->have_config) return fail(c, MSGW_ERR_ARG, "msgw_set_config has not been called");
     if (!c->have_column) return fail(c, MSGW_ERR_ARG, "msgw_set_column has not been called");
     if (!c->have_rays) return fail(c, MSGW_ERR_ARG, "msgw_upload_rays has not been called");
+    if (c->hprop && !c->have_hprop) return fail(c, MSGW_ERR_ARG, "HPROP is on: msgw_upload_hprop (lam, phi) has not been called");
+    return MSGW_OK;
+}
+
+// ---- HPROP_GLOBAL = True: its own per-stage kernel + the standalone column kernel
+size_t hprop_lds_bytes(int ng) { return stage_lds_bytes(ng) + sizeof(double) * (4 * (size_t)(ng - 1) + 2); }
+
+HpropArgs make_hprop_args(msgw_ctx *c, double dt, unsigned flags)
+{
+    HpropArgs h{};
+    h.s = make_stage_args(c, dt, flags);
+    h.lam = c->lam; h.phi = c->phi; h.kk = c->kk; h.ll = c->ll;
+    h.q_lam = c->q_lam; h.q_phi = c->q_phi; h.q_kk = c->q_kk; h.q_ll = c->q_ll;
+    h.uu = c->uu; h.vv = c->vv;
+    const double rot = 7.2921e-5;                                  // ROT_EARTH  (lib/libprop.py:4)
+    h.rad_earth = 6378e3;                                          // RAD_EARTH  (lib/libprop.py:3)
+    h.two_rot = 2 * rot;
+    h.df2c = 8 * (rot * rot);                                      // 8 * ROT_EARTH**2 (:489)
+    return h;
+}
+
+template <int STAGE>
+int launch_hprop_stage(msgw_ctx *c, const HpropArgs &h)
+{
+    const size_t lds = hprop_lds_bytes(c->ng);
+    if (c->sat_online) {
+        auto k = k_ray_stage_hprop<STAGE, true>;
+        if (int rc = ensure_lds(c, k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, h);
+    } else {
+        auto k = k_ray_stage_hprop<STAGE, false>;
+        if (int rc = ensure_lds(c, k, lds)) return rc;
+        hipLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, h);
+    }
+    HIPCHK(c, hipGetLastError());
+    return MSGW_OK;
+}
+
+int enqueue_steps_hprop(msgw_ctx *c, double dt, unsigned flags, int count)
+{
+    const HpropArgs h = make_hprop_args(c, dt, flags);
+    const ColArgs ca = make_col_args(c, dt, flags);
+    for (int step = 0; step < count; ++step) {
+        if (int rc = launch_hprop_stage<0>(c, h)) return rc;
+        if (int rc = column_stage<0>(c, ca)) return rc;
+        if (int rc = launch_hprop_stage<1>(c, h)) return rc;
+        if (int rc = column_stage<1>(c, ca)) return rc;
+        if (int rc = launch_hprop_stage<2>(c, h)) return rc;
+        if (int rc = column_stage<2>(c, ca)) return rc;
+    }
     return MSGW_OK;
 }
 
@@ -942,9 +997,19 @@ int msgw_destroy(msgw_ctx *c)
 int msgw_set_config(msgw_ctx *c, double bvf, double f0, double kappa, int saturate_online, int hprop)
 {
     if (!c) return MSGW_ERR_ARG;
-    if (hprop)
-        return fail(c, MSGW_ERR_UNSUP, "HPROP_GLOBAL=True (horizontal propagation) is outside this library's scope");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (hprop && !c->lam) {                                    // the six extra ray arrays of the spherical branch
+        const size_t padded = (((size_t)c->cap + TILE - 1) / TILE + 1) * TILE;
+        double **hp[] = {&c->lam, &c->phi, &c->q_lam, &c->q_phi, &c->q_kk, &c->q_ll};
+        for (double **p : hp) {
+            HIPCHK(c, hipMalloc(p, padded * sizeof(double)));
+            c->ray_bufs.push_back(*p);
+            HIPCHK(c, hipMemsetAsync(*p, 0, padded * sizeof(double), c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->bvf = bvf; c->f0 = f0; c->kappa = kappa; c->sat_online = saturate_online ? 1 : 0;
+    c->hprop = hprop ? 1 : 0;
     c->have_config = true;
     drop_graph(c);
     return MSGW_OK;
@@ -1025,9 +1090,39 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
     if (int rc = ensure_partial(c, c->blocks, (size_t)2 * (c->ng - 2))) return rc;
     if (int rc = ensure_groups(c)) return rc;
     c->have_rays = true;
+    c->have_hprop = false;                                     // lam, phi belong to the previous set of rays
     c->cnt.nray = n;
     c->cnt.blocks = c->blocks;
     drop_graph(c);
+    return MSGW_OK;
+}
+
+int msgw_upload_hprop(msgw_ctx *c, int64_t n, const double *lam, const double *phi)
+{
+    if (!c || !lam || !phi) return fail(c, MSGW_ERR_ARG, "NULL argument");
+    if (!c->hprop || !c->lam) return fail(c, MSGW_ERR_ARG, "HPROP is off (msgw_set_config(..., hprop = 1) first)");
+    if (!c->have_rays || n != c->n) return fail(c, MSGW_ERR_ARG, "call msgw_upload_rays first, with the same n");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t B = (size_t)n * sizeof(double);
+    HIPCHK(c, hipMemcpyAsync(c->lam, lam, B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->phi, phi, B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_hprop = true;
+    return MSGW_OK;
+}
+
+int msgw_download_hprop(msgw_ctx *c, int64_t n, int tendencies, double *lam, double *phi, double *kk, double *ll)
+{
+    if (!c) return MSGW_ERR_ARG;
+    if (!c->hprop || !c->have_hprop || n != c->n) return fail(c, MSGW_ERR_ARG, "no HPROP state of that size on the device");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t B = (size_t)n * sizeof(double);
+    const double *src[4] = {tendencies ? c->q_lam : c->lam, tendencies ? c->q_phi : c->phi,
+                            tendencies ? c->q_kk : c->kk, tendencies ? c->q_ll : c->ll};
+    double *dst[4] = {lam, phi, kk, ll};
+    for (int i = 0; i < 4; ++i)
+        if (dst[i]) HIPCHK(c, hipMemcpyAsync(dst[i], src[i], B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSGW_OK;
 }
 
@@ -1072,6 +1167,16 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
     const unsigned gflags = flags & ~(MSGW_NO_GRAPH | MSGW_TIME_KERNELS);
     if (time_kernels) c->kev_used = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (c->hprop) {                                            // HPROP_GLOBAL = True: its own per-stage chain
+        if (flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK | MSGW_RELAUNCH))
+            return fail(c, MSGW_ERR_UNSUP, "the fused direct saturation and the relaunch extension are not "
+                        "available with HPROP on (use msgw_saturation on downloaded arrays)");
+        c->cnt.persist_steps = 0;
+        if (int rc = enqueue_steps_hprop(c, dt, gflags, nsteps)) return rc;
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
+        return MSGW_OK;
+    }
     int done = 0;
     {
         bool used = false;
@@ -1125,8 +1230,13 @@ int msgw_rhs(msgw_ctx *c, double dt, unsigned flags, double *st_dens, double *st
 {
     if (int rc = ready(c)) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    const StageArgs sa = make_stage_args(c, dt, flags);
-    if (int rc = launch_probe(c, sa, c->sat_online != 0, true)) return rc;
+    if (c->hprop) {
+        const HpropArgs h = make_hprop_args(c, dt, flags);
+        if (int rc = launch_hprop_stage<3>(c, h)) return rc;
+    } else {
+        const StageArgs sa = make_stage_args(c, dt, flags);
+        if (int rc = launch_probe(c, sa, c->sat_online != 0, true)) return rc;
+    }
     const ColArgs ca = make_col_args(c, dt, flags);
     if (int rc = column_stage<3>(c, ca)) return rc;
     const size_t B = (size_t)c->n * sizeof(double), nc = c->ng - 1;

@@ -26,7 +26,7 @@ EXPORTS = [
     "msgw_abi_version", "msgw_last_error", "msgw_create", "msgw_destroy", "msgw_set_config",
     "msgw_set_column", "msgw_upload_rays", "msgw_step", "msgw_rhs", "msgw_project",
     "msgw_project_arrays", "msgw_saturation", "msgw_download_rays", "msgw_download_column",
-    "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters", "msgw_set_relaunch",
+    "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters", "msgw_set_relaunch", "msgw_upload_hprop", "msgw_download_hprop",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -77,6 +77,8 @@ def load_library():
     lib.msgw_set_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.msgw_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     lib.msgw_set_relaunch.argtypes = [C.c_void_p, C.c_double]
+    lib.msgw_upload_hprop.argtypes = [C.c_void_p, C.c_int64, _dp, _dp]
+    lib.msgw_download_hprop.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp, _dp, _dp, _dp]
     if lib.msgw_abi_version() != 1:
         raise MsgwError("libmsgwam_hip.so has an unexpected ABI version")
     _lib = lib
@@ -153,6 +155,18 @@ class Propagator:
 
     def set_tuning(self, blocks_per_cu=4, graph_steps=0):
         self._chk(self.lib.msgw_set_tuning(self.ctx, int(blocks_per_cu), int(graph_steps)), "msgw_set_tuning")
+
+    def upload_hprop(self, lam, phi):
+        """HPROP on: slots 1, 2 of the rays of the last upload_rays."""
+        a = [_c(np.broadcast_to(x, (self.n,))) for x in (lam, phi)]
+        self._chk(self.lib.msgw_upload_hprop(self.ctx, self.n, _p(a[0]), _p(a[1])), "msgw_upload_hprop")
+
+    def download_hprop(self, tendencies=False):
+        """HPROP on: (lam, phi, kk, ll), or their tendencies after rhs()."""
+        out = [np.empty(self.n) for _ in range(4)]
+        self._chk(self.lib.msgw_download_hprop(self.ctx, self.n, int(bool(tendencies)), *[_p(x) for x in out]),
+                  "msgw_download_hprop")
+        return out
 
     def set_relaunch(self, frac=1e-6):
         """EXTENSION (not in the reference): broken-ray fraction of the RELAUNCH flag."""

@@ -13,9 +13,9 @@ setters; `omega`; and the hot-path entry points `RK3`, `rhs_default`,
 fallback for those four: without the HIP library or a GPU they raise.
 
 Scope and deliberate differences (also in DESIGN.md):
-  * Only the `HPROP_GLOBAL = False` branch (the driver's, raytracer.py:38) with
-    scalar `bvf` is implemented; `HPROP_GLOBAL = True` raises NotImplementedError
-    at the first hot-path call.
+  * Only a scalar `bvf` is implemented.  Both `HPROP_GLOBAL` branches run on the GPU:
+    False (the driver's, raytracer.py:38) through the tuned kernels, True (lam, phi,
+    kk, ll evolve as well) through a plain kernel of its own.
   * `model_config['rhs']` must be one of this module's built-ins (`rhs_default`,
     `rhs_fixed_background`).  An arbitrary Python callable is opaque host code
     that cannot run on the device; it raises TypeError instead of silently
@@ -157,10 +157,6 @@ def release_device():
 
 
 def _check_scope():
-    if HPROP_GLOBAL:
-        raise NotImplementedError(
-            "HPROP_GLOBAL=True (horizontal propagation on the sphere) is outside the scope of the "
-            "MI355X path; set lprop.HPROP_GLOBAL = False as raytracer.py:38 does")
     if grid is None or grids is None:
         raise RuntimeError("lprop.grid / lprop.grids are not set (raytracer.py:76-77)")
     if np.ndim(model_config['bvf']) != 0:
@@ -173,10 +169,11 @@ def _same(a, b):
 
 def _sync_config_and_column(p, uu, vv, force_uv):
     cfg = (float(model_config['bvf']), float(model_config['phi0']), float(model_config['kappa']),
-           bool(model_config['saturate_online']))
+           bool(model_config['saturate_online']), bool(HPROP_GLOBAL))
     if _backend.cfg != cfg:
-        p.set_config(cfg[0], cfg[1], cfg[2], cfg[3], hprop=False)
+        p.set_config(cfg[0], cfg[1], cfg[2], cfg[3], hprop=cfg[4])
         _backend.cfg = cfg
+        _backend.rays = None                                     # lam, phi must be (re)uploaded with the rays
     col = _backend.col
     new = (np.asarray(grid, dtype=np.float64), np.asarray(grids, dtype=np.float64),
            np.asarray(rhobar, dtype=np.float64), np.asarray(pressure_gradient, dtype=np.float64))
@@ -198,11 +195,14 @@ _RAY_SLOTS = (0, 3, 4, 5, 6, 7, 8, 2)      # dens rr drr kk ll mm dmm phi
 def _sync_rays(p, var):
     st = (statics['dkk'], statics['dll'], statics['rr_mm_area'])     # KeyError as in :585-587
     res = _backend.rays
-    resident = (res is not None and all(res['in'][i] is var[i] for i in _RAY_SLOTS)
+    slots = _RAY_SLOTS + ((1,) if HPROP_GLOBAL else ())          # lam matters only with horizontal propagation
+    resident = (res is not None and all(res['in'][i] is var[i] for i in slots)
                 and all(a is b for a, b in zip(res['st'], st)))
     if not resident:
         dens, lam, phi, rr, drr, kk, ll, mm, dmm = [np.asarray(var[i], dtype=np.float64) for i in range(9)]
         p.upload_rays(dens, rr, drr, kk, ll, mm, dmm, phi, st[0], st[1], st[2])
+        if HPROP_GLOBAL:
+            p.upload_hprop(lam, phi)
     return not resident
 
 
@@ -240,7 +240,8 @@ def _flags_for(rhs):
 def rhs_default(dt, var_in):
     """lib/libprop.py:618-676 on the GPU: the 11 tendencies of
     [dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv].  With HPROP off the
-    tendencies of lam, phi, drr, kk, ll, dmm are identically zero."""
+    tendencies of lam, phi, drr, kk, ll, dmm are identically zero; with HPROP on
+    those of drr and dmm (ddrr_st = cgr_up - cgr_down = 0, :641, :645)."""
     return _rhs(dt, var_in, 0)
 
 
@@ -257,6 +258,9 @@ def _rhs(dt, var_in, flags):
     _backend.rays = dict(**{'in': list(var_in)}, st=(statics['dkk'], statics['dll'], statics['rr_mm_area']))
     _backend.col_uv = (var_in[9], var_in[10])
     z = lambda: np.zeros(np.shape(var_in[5]))
+    if HPROP_GLOBAL:                                             # lam, phi, kk, ll have tendencies too (:638-643)
+        lam, phi, kk, ll = p.download_hprop(tendencies=True)
+        return _pack([t['dens'], lam, phi, t['rr'], z(), kk, ll, t['mm'], z(), t['uu'], t['vv']])
     return _pack([t['dens'], z(), z(), t['rr'], z(), z(), z(), t['mm'], z(), t['uu'], t['vv']])
 
 
@@ -269,9 +273,12 @@ def RK3(dt, var):
     p.step(dt, 1, flags | _capi.NO_GRAPH)
     dens, rr, mm = p.download_rays()
     uu, vv = p.download_column()
-    out = [dens, np.array(var[1], dtype=np.float64), np.array(var[2], dtype=np.float64), rr,
-           np.array(var[4], dtype=np.float64), np.array(var[5], dtype=np.float64),
-           np.array(var[6], dtype=np.float64), mm, np.array(var[8], dtype=np.float64), uu, vv]
+    if HPROP_GLOBAL:
+        lam, phi, kk, ll = p.download_hprop()
+    else:
+        lam, phi, kk, ll = (np.array(var[i], dtype=np.float64) for i in (1, 2, 5, 6))
+    out = [dens, lam, phi, rr, np.array(var[4], dtype=np.float64), kk, ll, mm,
+           np.array(var[8], dtype=np.float64), uu, vv]
     # what is now on the device corresponds to `out`; frozen slots are equal by value
     _backend.rays = dict(**{'in': list(out)}, st=(statics['dkk'], statics['dll'], statics['rr_mm_area']))
     _backend.col_uv = (uu, vv)

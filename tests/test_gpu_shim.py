@@ -91,10 +91,6 @@ def test_scope_errors_are_loud():
     d = load("g3_rk3_coupled_driver")
     _configure_from(d, lprop)
     st = _obj(state_from(d, "in"))
-    lprop.HPROP_GLOBAL = True
-    with pytest.raises(NotImplementedError):
-        lprop.RK3(120.0, st)
-    lprop.HPROP_GLOBAL = False
     lprop.set_model_setup(rhs=lambda dt, v: v)
     with pytest.raises(TypeError):
         lprop.RK3(120.0, st)
@@ -126,3 +122,30 @@ def test_driver_matches_reference_loop(mode, nt, every):
             for k in ("wa", "flux_diag"):
                 want = d[f"s{n}_{k}"]
                 assert np.max(np.abs(H[k][n] - want)) <= 1e-10 * np.max(np.abs(want)), (n, k)
+
+
+def test_hprop_global_true_through_the_module_surface():
+    """lprop.HPROP_GLOBAL = True (libprop's own default): RK3 and rhs_default return all 11 slots, lam, phi,
+    kk, ll evolving, as the reference does (goldens generated by the reference, oracle/gen_golden.py g6)."""
+    import msgwam_amd.libprop as lprop
+    d = load("g6_hprop_rk3_coupled")
+    _configure_from(d, lprop)
+    lprop.HPROP_GLOBAL = True
+    try:
+        out = lprop.RK3(float(d["dt"]), _obj(state_from(d, "in")))
+        _check(out, d, "s1")
+        for _ in range(4):                     # feed the returned object back: state stays resident
+            out = lprop.RK3(float(d["dt"]), out)
+        _check(out, d, "s5")
+        assert not np.array_equal(out[2], d["in_phi"]) and not np.array_equal(out[5], d["in_kk"])
+        g = load("g6_hprop_rhs_sat1")
+        _configure_from(g, lprop)
+        lprop.HPROP_GLOBAL = True              # (_configure_from follows raytracer.py:38 and switches it off)
+        t = lprop.rhs_default(float(g["dt"]), _obj(state_from(g, "in")))
+        for i, k in enumerate(STATE_KEYS):
+            want = g[f"out_{k}"]
+            scale = np.max(np.abs(want))
+            assert np.all(np.abs(t[i] - want) <= 1e-10 * np.abs(want) + 1e-12 * scale), k
+    finally:
+        lprop.HPROP_GLOBAL = False
+        lprop.release_device()

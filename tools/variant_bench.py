@@ -27,3 +27,15 @@ for name, sat, flags, vec in (("plain", False, 0, False), ("online sat", True, 0
         res.append((dt / 100 * 1e6, p.counters()["persist_steps"]))
         p.close()
     print(f"{name:16s}: persistent {res[0][0]:7.1f} us/step (persist_steps {res[0][1]})   chain {res[1][0]:7.1f} us/step")
+# HPROP_GLOBAL = True: its own per-stage kernel (7 evolving slots per ray)
+p = _capi.Propagator(101, n)
+p.set_config(0.01, 0.4, 1.0, False, hprop=True)
+p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, uu, vv)
+phi = rng.uniform(-0.5, 0.5, n)
+p.upload_rays(sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], phi, sp["dkk"], sp["dll"], sp["area"])
+p.upload_hprop(np.zeros(n), phi)
+p.step(120.0, 10); p.sync()
+t0 = time.perf_counter(); p.step(120.0, 50); p.sync(); dt = time.perf_counter() - t0
+# per stage: read dens lam phi rr drr kk ll mm vol (+7 q, stages 1-2), write 6 (+6 q, stages 0-1): 27+14+18+12 words per step
+print(f"{'HPROP on':16s}: {dt / 50 * 1e6:7.1f} us/step  ({n * 50 / dt:.3e} ray-steps/s, {n * 71 * 8 / (dt / 50) / 1e9:.0f} GB/s of 71 words per ray-step)")
+p.close()
