@@ -101,3 +101,22 @@ def test_hprop_call_order_and_scope_errors():
         p.step(60.0, 1, _capi.DIRECT_SAT)
     p.step(60.0, 1)
     p.close()
+
+
+def test_hprop_through_the_allreduce_column_path(monkeypatch):
+    """Several ranks: the HPROP chain reduces its flux rows, all-reduces them (RCCL) and updates the column.
+    With a 1-rank communicator the all-reduce is the identity: results must be BITWISE the plain chain's."""
+    s, st = _random_case(20_000, 93, False, "vector", True)
+    st[0] = st[0] * 1e-3
+    p = _prop(s, st)
+    p.step(60.0, 4)
+    want = _state(p, st)
+    p.close()
+    monkeypatch.setenv("MSGW_FORCE_COLLECTIVE", "1")
+    p = _prop(s, st)
+    p.comm_init(_capi.comm_unique_id(), 0, 1)
+    p.step(60.0, 4)
+    got = _state(p, st)
+    p.close()
+    for k, a, b in zip(STATE_KEYS, got, want):
+        assert np.array_equal(a, b, equal_nan=True), k
