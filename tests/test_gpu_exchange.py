@@ -56,18 +56,19 @@ def test_exchange_off_falls_back_to_the_allreduce_chain(monkeypatch):
     p.close()
 
 
-@pytest.mark.parametrize("nranks,n", [(2, 120_000), (3, 50_001)])
-def test_ranks_as_processes_sharing_the_gpu(tmp_path, nranks, n):
+@pytest.mark.parametrize("nranks,n,sat,flags", [(2, 120_000, False, 0), (3, 50_001, False, 0),
+                                                 (2, 90_001, True, 0), (2, 70_000, False, _capi.DIRECT_SAT)])
+def test_ranks_as_processes_sharing_the_gpu(tmp_path, nranks, n, sat, flags):
     """nranks processes, each with its shard of the rays, advance together through the in-kernel
     exchange.  Against ONE process with all rays: per-ray state and column within summation-order
     noise (the ranks' partial sums are grouped differently), and the replicated columns of the ranks
     BITWISE equal to each other (every rank adds the same rows in the same order)."""
-    s, st = _random_case(n, 70 + nranks, False, "uniform", True)
+    s, st = _random_case(n, 70 + nranks, sat, "uniform", True)
     st[0] = st[0] * 1e-3                               # mild forcing: well-posed comparison
     calls = np.array([1, 2, 6])
     ref = make_prop(s, st)
     for k in calls:
-        ref.step(60.0, int(k))
+        ref.step(60.0, int(k), flags)
     want = gpu_state(ref, st)
     ref.close()
     dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = st
@@ -75,7 +76,7 @@ def test_ranks_as_processes_sharing_the_gpu(tmp_path, nranks, n):
     np.savez(case, grid=s.grid, grids=s.grids, rhobar=s.rhobar, pg=s.pressure_gradient, uu=uu, vv=vv, dens=dens,
              rr=rr, drr=drr, kk=kk, ll=ll, mm=mm, dmm=dmm, phi=phi, dkk=np.broadcast_to(s.dkk, (n,)),
              dll=np.broadcast_to(s.dll, (n,)), area=np.broadcast_to(s.rr_mm_area, (n,)), bvf=s.bvf, phi0=s.phi0,
-             kappa=s.kappa, sat=s.saturate_online, dt=60.0, calls=calls)
+             kappa=s.kappa, sat=s.saturate_online, dt=60.0, calls=calls, flags=flags)
     uid = _capi.comm_unique_id().hex()
     env = dict(os.environ, MSGW_EXCHANGE_ONLY="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "xch_rank_worker.py"), str(case), str(r),

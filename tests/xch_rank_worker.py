@@ -25,7 +25,7 @@ def main():
     cnt0 = p.counters()
     persist = []
     for nsteps in d["calls"]:
-        p.step(float(d["dt"]), int(nsteps))
+        p.step(float(d["dt"]), int(nsteps), int(d["flags"]) if "flags" in d.files else 0)
         persist.append(p.counters()["persist_steps"])
     dens, rr, mm = p.download_rays()
     uu, vv = p.download_column()
