@@ -132,9 +132,10 @@ int msgw_rhs(msgw_ctx *ctx, double dt, unsigned flags,
              double *st_dens, double *st_rr, double *st_mm,
              double *st_uu, double *st_vv, double *pm_flux);
 
-/* lprop.wave_projection(..., grid, var) (lib/libprop.py:92-197) of the resident
- * rays for var in {0,1,2} on an arbitrary uniform grid G [nG]; out is
- * [2][nG-1] for var 0 and [nG-1] otherwise (raytracer.py:213, :227). */
+/* lprop.wave_projection(..., grid, var) (lib/libprop.py:92-219) of the resident
+ * rays on an arbitrary uniform grid G [nG].  var 0, 1, 2 (cell centres): out is
+ * [2][nG-1] for var 0 and [nG-1] otherwise (raytracer.py:213, :227); var 3, 4
+ * (interfaces, :199-219): [nG] and [2][nG]. */
 int msgw_project(msgw_ctx *ctx, int var, const double *G, int nG, double *out);
 
 /* lprop.wave_projection(dens, lam, phi, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk,

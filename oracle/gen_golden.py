@@ -170,6 +170,10 @@ def gen_g2():
     d = {}
     G10 = np.linspace(0, 9000, 10)
     for gname, G in (("G10", G10), ("grid", grid), ("grids", grids)):
+        for var in (3, 4):                              # interface variants (:199-219): whole table only
+            d[f"edge_{gname}_var{var}"] = lprop.wave_projection(
+                one.copy(), 0 * one, 0 * one, edges[:, 0].copy(), edges[:, 1].copy(), 2e-4 * one, 1e-4 * one,
+                -1e-3 * one, -1e-3 * one, one, one, one, G, var=var)
         for var in (0, 1, 2):
             out = lprop.wave_projection(one.copy(), 0 * one, 0 * one, edges[:, 0].copy(), edges[:, 1].copy(),
                                         2e-4 * one, 1e-4 * one, -1e-3 * one, -1e-3 * one,
@@ -189,7 +193,7 @@ def gen_g2():
     grid, grids, uu, vv = configure(ngrid=101, grid_max=100e3)
     ic = random_rays(rng, 1000, grids, 0.3)
     for gname, G in (("grid", grid), ("grids", grids)):
-        for var in (0, 1, 2):
+        for var in (0, 1, 2, 3, 4):
             d[f"rand_{gname}_var{var}"] = lprop.wave_projection(
                 ic["dens"], ic["lam"], ic["phi"], ic["rr"] - .5 * ic["drr"], ic["rr"] + .5 * ic["drr"],
                 ic["kk"], ic["ll"], ic["mm"] - .5 * ic["dmm"], ic["mm"] + .5 * ic["dmm"],

@@ -123,7 +123,7 @@ def _projection_indices(rr_low, rr_up, G):
 
 def wave_projection(dens, rr_low, rr_up, kk, ll, mm_low, mm_up, phi,
                     dkk, dll, dmm, G, bvf, var=0, loop=False):
-    """lib/libprop.py:92-197 for var in {0, 1, 2}.
+    """lib/libprop.py:92-219 for var in {0, 1, 2, 3, 4}.
 
     `loop=False` is a vectorised closed form that accumulates in exactly the
     reference's order (ray-major, then cell), so it is bit-identical to
@@ -140,8 +140,19 @@ def wave_projection(dens, rr_low, rr_up, kk, ll, mm_low, mm_up, phi,
         payload = (cgr * dens,)                                  # :167
     elif var == 2:
         payload = (dens,)                                        # :184
+    elif var in (3, 4):
+        # :199-219: wave-action flux (3) / pseudo-momentum fluxes (4) at the INTERFACES nb = 1 .. len(G)-2: the sum
+        # over the rays straddling nb (nlow < nb < nup on the clipped indices), np.sum per interface as there
+        payload = (cgr * dens,) if var == 3 else (cgr * kk * dens, cgr * ll * dens)
+        out = np.zeros((len(payload), len(G)))
+        live = ~ood
+        for nb in range(1, len(G) - 1):
+            index = np.where((nlow < nb) & (nup > nb) & live)
+            for p, v in enumerate(payload):
+                out[p, nb] += np.sum(v[index] * phase_space_vol[index])
+        return out[0] if var == 3 else out
     else:
-        raise ValueError("oracle covers var 0, 1, 2 (3/4 have no caller)")
+        raise ValueError("var must be 0 .. 4")
     ncell = len(G) - 1
     out = np.zeros((len(payload), ncell))
 

@@ -1284,8 +1284,16 @@ static int run_projection(msgw_ctx *c, ProjArgs &a, bool expl, int np, const dou
         ca.partial = c->partial; ca.ranges = c->ranges; ca.flux = dflux;
         if ((rc = reduce_level1(c, ca))) break;
         if ((rc = launch_column_t<4, COL_REDUCE>(c, ca))) break;
-        if (hipMemcpyAsync(out, dflux, sizeof(double) * (size_t)np * ncp, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "D2H of projection failed"); break; }
+        std::vector<double> tmp;
+        double *dst = out;
+        if (a.boundary) { tmp.resize((size_t)np * ncp); dst = tmp.data(); }   // var 3/4: rows of nG values, last one 0
+        if (hipMemcpyAsync(dst, dflux, sizeof(double) * (size_t)np * ncp, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "D2H of projection failed"); break; }
         if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "sync failed in projection"); break; }
+        if (a.boundary)
+            for (int p = 0; p < np; ++p) {
+                std::memcpy(out + (size_t)p * nG, tmp.data() + (size_t)p * ncp, sizeof(double) * (size_t)ncp);
+                out[(size_t)p * nG + ncp] = 0.0;
+            }
     } while (0);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(dG);
@@ -1296,16 +1304,17 @@ static int run_projection(msgw_ctx *c, ProjArgs &a, bool expl, int np, const dou
 int msgw_project(msgw_ctx *c, int var, const double *G, int nG, double *out)
 {
     if (int rc = ready(c)) return rc;
-    if (var < 0 || var > 2) return fail(c, MSGW_ERR_UNSUP, "wave_projection var=%d: only 0, 1, 2 have callers", var);
+    if (var < 0 || var > 4) return fail(c, MSGW_ERR_ARG, "wave_projection var=%d: must be 0 .. 4", var);
     if (!G || !out || nG < 3) return fail(c, MSGW_ERR_ARG, "bad projection grid");
     HIPCHK(c, hipSetDevice(c->device));
     ProjArgs a{};
-    a.n = c->n; a.nG = nG; a.var = var;
+    // var 3 / 4 (:199-219): the payloads of var 1 / var 0, summed at the interfaces
+    a.n = c->n; a.nG = nG; a.var = (var == 3) ? 1 : (var == 4 ? 0 : var); a.boundary = var >= 3;
     a.bvf2 = std::pow(c->bvf, 2.0); a.f_uni = c->f_uni; a.dz = G[1] - G[0];
     a.cdz = 1.0 / a.dz; a.mk_ok = markstein_ok(a.dz);
     a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
                   c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0, c->src_dens, c->src_rr, c->src_mm, c->cgbuf};
-    return run_projection(c, a, false, var == 0 ? 2 : 1, G, nG, out);
+    return run_projection(c, a, false, (var == 0 || var == 4) ? 2 : 1, G, nG, out);
 }
 
 int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const double *dens,
@@ -1314,7 +1323,7 @@ int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const doubl
                         const double *dmm, const double *fray, const double *G, int nG, double *out)
 {
     if (!c) return MSGW_ERR_ARG;
-    if (var < 0 || var > 2) return fail(c, MSGW_ERR_UNSUP, "wave_projection var=%d: only 0, 1, 2 have callers", var);
+    if (var < 0 || var > 4) return fail(c, MSGW_ERR_ARG, "wave_projection var=%d: must be 0 .. 4", var);
     if (n < 1 || !G || !out || nG < 3) return fail(c, MSGW_ERR_ARG, "bad projection arguments");
     const double *h[11] = {dens, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, fray};
     for (const double *p : h) if (!p) return fail(c, MSGW_ERR_ARG, "NULL array");
@@ -1333,11 +1342,11 @@ int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const doubl
     }
     if (rc == MSGW_OK) {
         ProjArgs a{};
-        a.n = n; a.nG = nG; a.var = var;
+        a.n = n; a.nG = nG; a.var = (var == 3) ? 1 : (var == 4 ? 0 : var); a.boundary = var >= 3;
         a.bvf2 = std::pow(bvf, 2.0); a.f_uni = 0.0; a.dz = G[1] - G[0];
         a.cdz = 1.0 / a.dz; a.mk_ok = markstein_ok(a.dz);
         a.e = ProjExplicit{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]};
-        rc = run_projection(c, a, true, var == 0 ? 2 : 1, G, nG, out);
+        rc = run_projection(c, a, true, (var == 0 || var == 4) ? 2 : 1, G, nG, out);
     }
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(buf);

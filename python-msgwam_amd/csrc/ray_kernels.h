@@ -912,7 +912,8 @@ struct ProjArgs {
     long long n;
     int nG;               // points of G; output has nG-1 levels
     int tiles_per_block;
-    int var;
+    int var;              // payload: 0 pseudo-momentum fluxes (NP = 2), 1 wave-action flux, 2 wave action
+    int boundary;         // 1: var 3 / 4 (:199-219) -- sums at the interfaces nb with nlow < nb < nup, unit weight
     double bvf2, f_uni, dz, cdz;
     int mk_ok;
     RayPtrs r;            // resident rays   (EXPL = false)
@@ -986,6 +987,10 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             deposit_indices<NP>(lo[r], up[r], valid[r], a.dz, a.cdz, a.mk_ok, nG - 2, nlo[r], nup[r]);
+            if (a.boundary) {            // interfaces nlow+1 .. nup-1 (:205, :216); weight |G[nb+1]-G[nb]|/dz = 1
+                nlo[r] += 1;
+                lo[r] = -1e300; up[r] = 1e300;
+            }
             const double f = (FVEC || EXPL) ? ff[r] : a.f_uni;
             double kh2, m2, vk2, om, cgr;
             dispersion(kk[r], ll[r], mmid[r], f * f, a.bvf2, kh2, m2, vk2, om, cgr);

@@ -184,9 +184,14 @@ class Propagator:
                                     _p(out["mm"]), _p(out["uu"]), _p(out["vv"]), _p(out["pm_flux"])), "msgw_rhs")
         return out
 
+    @staticmethod
+    def _proj_shape(var, nG):
+        """lib/libprop.py:147, :165, :182, :200, :210: cell centres for var 0-2, interfaces for var 3, 4."""
+        return {0: (2, nG - 1), 1: (nG - 1,), 2: (nG - 1,), 3: (nG,), 4: (2, nG)}[int(var)]
+
     def project(self, var, G):
         G = _c(G)
-        out = np.empty((2, len(G) - 1)) if var == 0 else np.empty(len(G) - 1)
+        out = np.empty(self._proj_shape(var, len(G)))
         self._chk(self.lib.msgw_project(self.ctx, int(var), _p(G), len(G), _p(out)), "msgw_project")
         return out
 
@@ -195,7 +200,7 @@ class Propagator:
         fray = coriolis(np.asarray(phi, dtype=np.float64))
         a = [_c(np.broadcast_to(x, (n,))) for x in (dens, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, fray)]
         G = _c(G)
-        out = np.empty((2, len(G) - 1)) if var == 0 else np.empty(len(G) - 1)
+        out = np.empty(self._proj_shape(var, len(G)))
         self._chk(self.lib.msgw_project_arrays(self.ctx, n, int(var), float(bvf), *[_p(x) for x in a],
                                                _p(G), len(G), _p(out)), "msgw_project_arrays")
         return out

@@ -22,7 +22,6 @@ Scope and deliberate differences (also in DESIGN.md):
     running a CPU path.
   * `RK3` builds its 11-slot object array slot by slot, so `nray == ngrid-1`
     works (the reference crashes there, lib/libprop.py:668-674).
-  * `wave_projection` supports var 0, 1, 2 (var 3, 4 have no caller).
 Column/initial-condition helpers (`set_hydrostatics`, `set_pressure_gradient`,
 `velocities_*`, `omega`) are one-off O(ngrid)/O(nray) host-side setup in numpy,
 as in the reference.
@@ -301,10 +300,9 @@ def saturation(dt, dens, rr_center, rr_center_st, drr, drr_st, kk, ll, mm_center
 
 def wave_projection(dens, lam, phi, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, grid,
                     var=0):
-    """lib/libprop.py:92-221 on the GPU for var in {0, 1, 2}."""
-    if var not in (0, 1, 2):
-        raise NotImplementedError("wave_projection var 3/4 (interface variants) have no caller in the "
-                                  "reference and are not implemented")
+    """lib/libprop.py:92-221 on the GPU: var 0, 1, 2 at the cell centres, var 3, 4 at the interfaces."""
+    if var not in (0, 1, 2, 3, 4):
+        raise ValueError("wave_projection: var must be 0 .. 4 (lib/libprop.py:97-102)")
     n = len(dens)
     ng = len(globals()['grid']) if globals()['grid'] is not None else len(grid)
     p = _backend.context(ng, n)

@@ -168,7 +168,7 @@ def test_projection_vs_reference_golden():
     st = [r[k] for k in STATE_KEYS[:9]] + [uu, uu]
     p = make_prop(s, st)
     for gname, G in (("grid", g101), ("grids", grids)):
-        for var in (0, 1, 2):
+        for var in (0, 1, 2, 3, 4):                    # 3, 4: the interface variants (lib/libprop.py:199-219)
             want = d[f"rand_{gname}_var{var}"]
             got_res = p.project(var, G)
             got_arr = p.project_arrays(var, 0.01, r["dens"], r["phi"], r["rr"] - .5 * r["drr"],
@@ -184,6 +184,14 @@ def test_projection_vs_reference_golden():
             got = p.project_arrays(2, 0.01, one, 0 * one, e[i:i + 1, 0], e[i:i + 1, 1], 2e-4 * one, 1e-4 * one,
                                    -1e-3 * one, -1e-3 * one, one, one, one, G)
             np.testing.assert_array_equal(got, d[f"edgerows_{gname}_var2"][i], err_msg=f"{gname} ray {i}")
+        # the whole edge table at the interfaces (payload x volume of the straddling rays, unit weights)
+        n = len(e)
+        o = np.ones(n)
+        for var in (3, 4):
+            got = p.project_arrays(var, 0.01, o, 0 * o, e[:, 0], e[:, 1], 2e-4 * o, 1e-4 * o, -1e-3 * o, -1e-3 * o,
+                                   o, o, o, G)
+            want = d[f"edge_{gname}_var{var}"]
+            assert got.shape == want.shape and prof_err(got, want) <= 1e-13, (gname, var)
     p.close()
 
 

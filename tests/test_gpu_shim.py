@@ -95,8 +95,8 @@ def test_scope_errors_are_loud():
     with pytest.raises(TypeError):
         lprop.RK3(120.0, st)
     lprop.set_model_setup(rhs=lprop.rhs_default)
-    with pytest.raises(NotImplementedError):
-        lprop.wave_projection(*([np.ones(4)] * 12), d["grid"], var=3)
+    with pytest.raises(ValueError):
+        lprop.wave_projection(*([np.ones(4)] * 12), d["grid"], var=5)
     lprop.release_device()
 
 

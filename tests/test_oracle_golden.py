@@ -202,3 +202,16 @@ def test_hprop_rk3_rows_bit_exact():
             for i, k in enumerate(STATE_KEYS):
                 assert np.array_equal(st[i], d[f"s{n}_{k}"], equal_nan=True), (n, k)
     assert not np.array_equal(st[2], d["in_phi"]) and not np.array_equal(st[5], d["in_kk"])   # they really evolve
+
+
+def test_projection_interface_variants_bit_exact():
+    """wave_projection var 3 / 4 (lib/libprop.py:199-219, no caller in the reference but part of its surface)."""
+    d = load("g2_projection")
+    g101 = d["grid101"]
+    r = {k: d["rand_" + k] for k in ("dens", "phi", "rr", "drr", "kk", "ll", "mm", "dmm", "dkk", "dll")}
+    for gname, G in (("grid", g101), ("grids", .5 * (g101[:-1] + g101[1:]))):
+        for var in (3, 4):
+            got = orc.wave_projection(r["dens"], r["rr"] - .5 * r["drr"], r["rr"] + .5 * r["drr"], r["kk"], r["ll"],
+                                      r["mm"] - .5 * r["dmm"], r["mm"] + .5 * r["dmm"], r["phi"], r["dkk"], r["dll"],
+                                      r["dmm"], G, float(d["bvf"]), var=var)
+            assert np.array_equal(got, d[f"rand_{gname}_var{var}"]), (gname, var)
