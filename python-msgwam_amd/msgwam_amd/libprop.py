@@ -106,6 +106,106 @@ def omega(kk, ll, mm, phi):
     return np.sqrt((bvf ** 2 * (kk ** 2 + ll ** 2) + ff ** 2 * mm ** 2) / (kk ** 2 + ll ** 2 + mm ** 2))
 
 
+
+# ----------------------------------------------------------------------------
+# The building blocks of the reference's rhs_default as host-side numpy helpers (same names, argument
+# orders and module globals as lib/libprop.py).  They are here for scripts that call them directly, e.g.
+# to plot group velocities; the GPU path has its own implementation and never calls them.
+# ----------------------------------------------------------------------------
+def _horizontal_norm(rr):
+    return RAD_EARTH + rr
+
+
+def gradients(lam_ray, phi_ray, rr_ray, uu, vv):
+    """lib/libprop.py:328-366: winds and wind gradients at the rays, shape (4, 3) + rays.shape:
+    [0] = (u, v, w), [1] = grad u, [2] = grad v, [3] = grad w in (lam, phi, r).  Only the vertical shear
+    is non-zero in the 1-D column."""
+    dz = np.diff(grid[:2])[0]
+    out = np.zeros((4, 3) + np.shape(lam_ray))
+    out[0, 0] = np.interp(rr_ray, grids, uu)
+    out[0, 1] = np.interp(rr_ray, grids, vv)
+    out[1, 2] = np.interp(rr_ray, grid[1:-1], (uu[1:] - uu[:-1]) / dz)
+    out[2, 2] = np.interp(rr_ray, grid[1:-1], (vv[1:] - vv[:-1]) / dz)
+    return out
+
+
+def cg_rr(kk, ll, mm, lam, phi, rr):
+    """lib/libprop.py:434-448: vertical group velocity."""
+    ff = 2 * ROT_EARTH * np.sin(phi)
+    om = omega(kk, ll, mm, phi)
+    return - mm * (om ** 2 - ff ** 2) / om / (kk ** 2 + ll ** 2 + mm ** 2)
+
+
+def _cg_horizontal(kh, kk, ll, mm, phi, wind_ray):
+    if not HPROP_GLOBAL:                                   # :406, :430
+        return np.zeros(np.shape(kk))
+    bvf = model_config['bvf']
+    om = omega(kk, ll, mm, phi)
+    return kh / om / (kk ** 2 + ll ** 2 + mm ** 2) * (bvf ** 2 - om ** 2) + wind_ray
+
+
+def cg_lambda(kk, ll, mm, lam, phi, rr, uu, vv):
+    """lib/libprop.py:385-407: zonal group velocity (zero with HPROP_GLOBAL off)."""
+    return _cg_horizontal(kk, kk, ll, mm, phi, np.interp(rr, grids, uu))
+
+
+def cg_phi(kk, ll, mm, lam, phi, rr, uu, vv):
+    """lib/libprop.py:409-431: meridional group velocity (zero with HPROP_GLOBAL off)."""
+    return _cg_horizontal(ll, kk, ll, mm, phi, np.interp(rr, grids, vv))
+
+
+def dk_dt(kk, ll, mm, lam, phi, rr, uu, vv):
+    """lib/libprop.py:451-471: tendency of the zonal wavenumber (zero with HPROP_GLOBAL off)."""
+    if not HPROP_GLOBAL:
+        return np.zeros(np.shape(kk))
+    vel = gradients(lam, phi, rr, uu, vv)
+    gradient = (kk * vel[1, 0] + ll * vel[2, 0]) / _horizontal_norm(rr) / np.cos(phi)
+    return kk / _horizontal_norm(rr) * (np.tan(phi) * cg_phi(kk, ll, mm, lam, phi, rr, uu, vv)
+                                        - cg_rr(kk, ll, mm, lam, phi, rr)) - gradient
+
+
+def dl_dt(kk, ll, mm, lam, phi, rr, uu, vv):
+    """lib/libprop.py:474-499: tendency of the meridional wavenumber (zero with HPROP_GLOBAL off)."""
+    if not HPROP_GLOBAL:
+        return np.zeros(np.shape(kk))
+    vel = gradients(lam, phi, rr, uu, vv)
+    gradient = (kk * vel[1, 1] + ll * vel[2, 1]) / _horizontal_norm(rr)
+    df2_dphi = 8 * ROT_EARTH ** 2 * np.sin(phi) * np.cos(phi) * 1
+    return - (ll * cg_rr(kk, ll, mm, lam, phi, rr)
+              + kk * np.tan(phi) * cg_lambda(kk, ll, mm, lam, phi, rr, uu, vv)
+              + mm ** 2 / 2 / omega(kk, ll, mm, phi) / (kk ** 2 + ll ** 2 + mm ** 2) * df2_dphi) \
+        / _horizontal_norm(rr) - gradient
+
+
+def dm_dt(kk, ll, mm, lam, phi, rr, uu, vv):
+    """lib/libprop.py:502-520: tendency of the vertical wavenumber."""
+    vel = gradients(lam, phi, rr, uu, vv)
+    gradient = kk * vel[1, 2] + ll * vel[2, 2]
+    return (kk * cg_lambda(kk, ll, mm, lam, phi, rr, uu, vv)
+            + ll * cg_phi(kk, ll, mm, lam, phi, rr, uu, vv)) / _horizontal_norm(rr) - gradient
+
+
+def du_dt(vv, pm_flux_gradient):
+    """lib/libprop.py:523-539: zonal mean-flow tendency."""
+    ff = 2 * ROT_EARTH * np.sin(model_config['phi0'])
+    return ff * vv - rhobar ** -1 * (pressure_gradient[0] + pm_flux_gradient)
+
+
+def dv_dt(uu, pm_flux_gradient):
+    """lib/libprop.py:542-558: meridional mean-flow tendency."""
+    ff = 2 * ROT_EARTH * np.sin(model_config['phi0'])
+    return -ff * uu - rhobar ** -1 * (pressure_gradient[1] + pm_flux_gradient)
+
+
+def velocities_tanh(lam, phi, rr):
+    """lib/libprop.py:222-246: jet, Gaussian in latitude and tanh in height; (4, 3) + lam.shape with the
+    wind written into the whole first row, as there."""
+    c = model_config
+    shape = np.exp(-(phi - c['phi0']) ** 2 / 2 / c['sig_phi'] ** 2) * (np.tanh((rr - c['rr0']) / c['sig_rr']) + 1) * 0.5
+    out = np.zeros((4, 3) + np.shape(lam))
+    out[0] = c['u0'] * shape
+    return out
+
 # ----------------------------------------------------------------------------
 # device backend
 # ----------------------------------------------------------------------------
