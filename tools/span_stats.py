@@ -14,7 +14,7 @@ p.set_config(0.01, 0.0, 1.0, False)
 p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, uu, vv)
 p.upload_rays(sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], sp["phi"], sp["dkk"], sp["dll"], sp["area"])
 done = 0
-for k in (0, 20, 220, 1020):
+for k in (0, 30, 130, 230, 530, 1030):
     p.step(120.0, k - done); done = k
     _, rr, mm = p.download_rays()
     lo, up = rr - 75.0, rr + 75.0
