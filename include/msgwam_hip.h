@@ -14,10 +14,16 @@
  * No C++ exceptions cross this boundary.  One context per GPU; a context is
  * not thread-safe.  NaN/inf propagate as in numpy, nothing traps.
  *
- * All floating-point data is float64 (the reference is float64 throughout).
- * Scope: the HPROP_GLOBAL = False branch with scalar bvf, i.e. the driver's
- * configuration (raytracer.py:38); there only dens, rr, mm and the uu, vv
- * columns evolve, so only those are ever copied back.
+ * All floating-point data crossing this boundary is float64 (the reference is
+ * float64 throughout).  The resident ray state is float64 by default -- that is
+ * the reference-parity mode -- or float32 when the context is created with
+ * MSGW_DTYPE_F32 (BASELINE config 5: half the bytes per ray, float32 per-ray
+ * arithmetic; flux rows, their reduction and the mean-flow column stay float64).
+ * Scope: scalar bvf; both HPROP_GLOBAL branches (lib/libprop.py:5).  With
+ * HPROP_GLOBAL = False, the driver's configuration (raytracer.py:38), only dens,
+ * rr, mm and the uu, vv columns evolve, so only those are copied
+ * back; HPROP_GLOBAL = True adds lam, phi, kk, ll (msgw_upload_hprop /
+ * msgw_download_hprop; float64 contexts only).
  */
 #ifndef MSGWAM_HIP_H
 #define MSGWAM_HIP_H
@@ -30,7 +36,7 @@ extern "C" {
 
 typedef struct msgw_ctx msgw_ctx;
 
-#define MSGW_ABI_VERSION 1
+#define MSGW_ABI_VERSION 2
 
 /* error codes */
 #define MSGW_OK            0
@@ -39,6 +45,15 @@ typedef struct msgw_ctx msgw_ctx;
 #define MSGW_ERR_NOGPU    -3   /* no usable gfx950 device                    */
 #define MSGW_ERR_RCCL     -4   /* RCCL missing or a collective failed        */
 #define MSGW_ERR_UNSUP    -5   /* outside the supported scope (e.g. HPROP)   */
+
+/* flags of msgw_create_ex */
+#define MSGW_DTYPE_F32          1u  /* resident ray state and per-ray arithmetic in float32 (default: float64) */
+
+/* msgw_counters_t.transport: how several ranks sum their flux rows */
+#define MSGW_TRANSPORT_NONE       0   /* one rank */
+#define MSGW_TRANSPORT_RCCL       1   /* ncclAllReduce once per RK stage (lagged launch chain) */
+#define MSGW_TRANSPORT_HOST_SHM   2   /* inside the persistent kernel, through a node-shared host segment */
+#define MSGW_TRANSPORT_DEVICE_IPC 3   /* inside the persistent kernel, peer writes into HIP-IPC-mapped HBM (xGMI) */
 
 /* flags of msgw_step / msgw_rhs */
 #define MSGW_FIXED_BACKGROUND   1u  /* rhs hook that zeroes slots 9,10: no deposit, column frozen */
@@ -51,7 +66,8 @@ typedef struct msgw_ctx msgw_ctx;
                                        rr + drr/2 < grid[0]) or whose dens fell below frac x its source value
                                        (msgw_set_relaunch) is recycled to the (dens, rr, mm) it was uploaded with.
                                        Comparisons with NaN are false.  Checked once per RK3 step, after the
-                                       direct saturation when that is on.  Runs in the per-stage kernels.  */
+                                       direct saturation when that is on.  A compile-time variant of the persistent
+                                       kernel and of the per-stage kernels.  */
 
 /* counters filled by msgw_counters */
 typedef struct {
@@ -68,7 +84,9 @@ typedef struct {
                                     or fused fixed-background kernel (0 = one launch per RK stage)       */
     int32_t exchange;            /* 1: multi-rank steps use the in-kernel node-level flux exchange */
     int32_t persist_resident_tiles; /* tiles per workgroup the last persistent launch kept in registers */
-    int32_t reserved_;
+    int32_t elem_bytes;          /* bytes per element of the resident ray state: 8 (float64) or 4 (float32) */
+    int32_t transport;           /* MSGW_TRANSPORT_* of the communicator                         */
+    int32_t tenants;             /* ranks of the communicator that share this rank's device (1 in production) */
 } msgw_counters_t;
 
 /* HPROP on: slots 1 and 2 (lam, phi) of the rays uploaded by the last msgw_upload_rays (same n). */
@@ -88,6 +106,8 @@ const char *msgw_last_error(const msgw_ctx *ctx);
 /* Create a context on HIP device `device` for at most nray_cap rays on a
  * column with ngrid interfaces (len(lprop.grid), raytracer.py:74-77). */
 int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid);
+/* The same with MSGW_DTYPE_* flags (no reference counterpart: the reference is float64 numpy). */
+int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsigned create_flags);
 int msgw_destroy(msgw_ctx *ctx);
 
 /* model_config scalars read by the hot path (lib/libprop.py:380, :534, :582-584,
@@ -170,7 +190,10 @@ int msgw_sync(msgw_ctx *ctx);
 
 /* Multi-GPU (no reference counterpart: the reference is single-process).
  * Rays are sharded across ranks; the per-stage flux profile (2 x (ngrid-2)
- * float64) is all-reduced with RCCL before the mean-flow update.
+ * float64) is summed over the ranks before the mean-flow update: inside the
+ * persistent kernel by peer writes into HIP-IPC-mapped HBM (xGMI), with a
+ * node-shared host segment and an RCCL all-reduce chain as fallbacks
+ * (msgw_counters_t.transport says which).
  * msgw_comm_unique_id fills a 128-byte ncclUniqueId on rank 0; every rank then
  * calls msgw_comm_init with the same id. */
 int msgw_comm_unique_id(void *id128);

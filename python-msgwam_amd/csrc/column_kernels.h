@@ -137,49 +137,4 @@ struct Red1Args {
     const int *ranges;
     double *out;
 };
-__global__ void __launch_bounds__(COL_BLOCK) k_flux_reduce1(const Red1Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *s_seg = lds;                                              // [nseg][ncols]
-    int *s_rng = reinterpret_cast<int *>(s_seg + (size_t)a.nseg * a.ncols);
-    const int tid = threadIdx.x;
-    const int r0 = (int)((long long)blockIdx.x * a.nblocks / gridDim.x);
-    const int r1 = (int)((long long)(blockIdx.x + 1) * a.nblocks / gridDim.x);
-    const int nr = r1 - r0;
-    for (int i = tid; i < 2 * nr; i += COL_BLOCK) s_rng[i] = a.ranges[2 * r0 + i];
-    __syncthreads();
-    for (int idx = tid; idx < a.nseg * a.ncols; idx += COL_BLOCK) {
-        const int seg = idx / a.ncols, col = idx - seg * a.ncols;
-        const int c = col % a.ncp;
-        const int b0 = (int)((long long)seg * nr / a.nseg), b1 = (int)((long long)(seg + 1) * nr / a.nseg);
-        const double *src = a.partial + (size_t)r0 * a.ncols + col;
-        double acc = 0.0;
-        for (int b = b0; b < b1; b += 16) {                  // 16 loads in flight per thread
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = src[(size_t)min(b + u, b1 - 1) * a.ncols];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int bb = min(b + u, b1 - 1);
-                const bool in = (b + u < b1) && (c >= s_rng[2 * bb]) && (c < s_rng[2 * bb + 1]);
-                acc = acc + (in ? v[u] : 0.0);
-            }
-        }
-        s_seg[idx] = acc;
-    }
-    __syncthreads();
-    for (int col = tid; col < a.ncols; col += COL_BLOCK) {
-        double tot = s_seg[col];
-        for (int s = 1; s < a.nseg; ++s) tot = tot + s_seg[s * a.ncols + col];
-        a.out[(size_t)blockIdx.x * a.ncols + col] = tot;
-    }
-}
-
-// slopes of np.interp(., grids, rhobar) (lib/libprop.py:595), once per column upload
-__global__ void k_rho_slopes(int nc, const double *grids, const double *rhobar, double *slrho)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < nc - 1) slrho[j] = (rhobar[j + 1] - rhobar[j]) / (grids[j + 1] - grids[j]);
-}
-
 }   // namespace msgw

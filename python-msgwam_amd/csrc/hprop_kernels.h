@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
     int wmin = INT_MAX, wmax = INT_MIN;
     double acc[2][1] = {{0.0}, {0.0}};
     for (int t = 0; t < a.tiles_per_block; ++t) {
-        const long long base = start + (long long)t * TILE;
+        const long long base = start + (long long)t * Real<double>::TILE;
         if (base >= end) break;
         const long long e0 = base + 2 * tid;
         const unsigned int i0 = (unsigned int)(e0 * 8);
@@ -62,14 +62,14 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
         double dens[2], lam[2], phi[2], rr[2], drr[2], kk[2], ll[2], mm[2], vol[2], pvf[2] = {1.0, 1.0};
         double qd[2] = {0, 0}, qla[2] = {0, 0}, qph[2] = {0, 0}, qr[2] = {0, 0}, qk[2] = {0, 0}, ql[2] = {0, 0},
                qm[2] = {0, 0};
-        load2(a.r.dens, i0, dens); load2(h.lam, i0, lam); load2(h.phi, i0, phi); load2(a.r.rr, i0, rr);
-        load2(a.r.drr, i0, drr); load2(h.kk, i0, kk); load2(h.ll, i0, ll); load2(a.r.mm, i0, mm);
-        load2(a.r.vol, i0, vol);
-        if (SAT) load2(a.r.pvf, i0, pvf);
+        loadv(a.r.dens, i0, dens); loadv(h.lam, i0, lam); loadv(h.phi, i0, phi); loadv(a.r.rr, i0, rr);
+        loadv(a.r.drr, i0, drr); loadv(h.kk, i0, kk); loadv(h.ll, i0, ll); loadv(a.r.mm, i0, mm);
+        loadv(a.r.vol, i0, vol);
+        if (SAT) loadv(a.r.pvf, i0, pvf);
         if (STAGE == 1 || STAGE == 2) {
-            load2(h.q_lam, i0, qla); load2(h.q_phi, i0, qph); load2(a.r.q_rr, i0, qr); load2(h.q_kk, i0, qk);
-            load2(h.q_ll, i0, ql); load2(a.r.q_mm, i0, qm);
-            if (SAT) load2(a.r.q_dens, i0, qd);
+            loadv(h.q_lam, i0, qla); loadv(h.q_phi, i0, qph); loadv(a.r.q_rr, i0, qr); loadv(h.q_kk, i0, qk);
+            loadv(h.q_ll, i0, ql); loadv(a.r.q_mm, i0, qm);
+            if (SAT) loadv(a.r.q_dens, i0, qd);
         }
         double lo[2], up[2], pay[2][2];
         double n_dens[2], n_lam[2], n_phi[2], n_rr[2], n_kk[2], n_ll[2], n_mm[2];
@@ -81,11 +81,11 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
             const double f2 = f * f;
             double kh2, m2, vk2, om, cgr;
             dispersion(kk[r], ll[r], mm[r], f2, a.bvf2, kh2, m2, vk2, om, cgr);   // :369-383, :434-448
-            const Bracket bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
+            const Bracket<double> bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
             const double4 sh = s_sh[bk.j];
             const double gu = interp_eval(rr[r], bk, sh.x, sh.y);                   // du/dz at the ray (:355)
             const double gv = interp_eval(rr[r], bk, sh.z, sh.w);                   // dv/dz at the ray (:356)
-            const Bracket bu = interp_locate(rr[r], s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+            const Bracket<double> bu = interp_locate(rr[r], s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
             const double4 uv = s_uv[bu.j];
             const double uu_ray = interp_eval(rr[r], bu, uv.x, uv.y);               // :357
             const double vv_ray = interp_eval(rr[r], bu, uv.z, uv.w);               // :358
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
             if (SAT) {                                                              // :647-651 -> :561-615
                 const double rr_f = rr[r] + st_rr * a.dt;
                 const double mm_f = mm[r] + st_mm * a.dt;
-                const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+                const Bracket<double> br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
                 const double2 rh = s_rho2[br.j];
                 const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);
                 const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);        // omega(kk, ll, mm, phi0) (:597)
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
                 double yn[7];
 #pragma unroll
                 for (int v = 0; v < 7; ++v) {                                       // :693-698
-                    if (STAGE == 0) { q[v] = a.dt * st[v]; yn[v] = y[v] + div_const(q[v], 3.0, THIRD_RN, 1); }
+                    if (STAGE == 0) { q[v] = a.dt * st[v]; yn[v] = y[v] + div_const(q[v], 3.0, third_rn<double>(), 1); }
                     else if (STAGE == 1) { q[v] = a.dt * st[v] - RK_A1 * q[v]; yn[v] = y[v] + RK_B1 * q[v]; }
                     else { q[v] = a.dt * st[v] - RK_A2 * q[v]; yn[v] = y[v] + RK_B2 * q[v]; }
                 }
@@ -139,21 +139,21 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
         }
         if (valid[0]) {                                        // only the owner stores (pairs never straddle)
             if (STAGE == 3) {
-                store2(a.r.q_dens, i0, n_dens); store2(h.q_lam, i0, n_lam); store2(h.q_phi, i0, n_phi);
-                store2(a.r.q_rr, i0, n_rr); store2(h.q_kk, i0, n_kk); store2(h.q_ll, i0, n_ll);
-                store2(a.r.q_mm, i0, n_mm);
+                storev(a.r.q_dens, i0, n_dens); storev(h.q_lam, i0, n_lam); storev(h.q_phi, i0, n_phi);
+                storev(a.r.q_rr, i0, n_rr); storev(h.q_kk, i0, n_kk); storev(h.q_ll, i0, n_ll);
+                storev(a.r.q_mm, i0, n_mm);
             } else {
-                if (SAT) store2(a.r.dens, i0, n_dens);
-                store2(h.lam, i0, n_lam); store2(h.phi, i0, n_phi); store2(a.r.rr, i0, n_rr);
-                store2(h.kk, i0, n_kk); store2(h.ll, i0, n_ll); store2(a.r.mm, i0, n_mm);
+                if (SAT) storev(a.r.dens, i0, n_dens);
+                storev(h.lam, i0, n_lam); storev(h.phi, i0, n_phi); storev(a.r.rr, i0, n_rr);
+                storev(h.kk, i0, n_kk); storev(h.ll, i0, n_ll); storev(a.r.mm, i0, n_mm);
                 if (STAGE != 2) {
-                    if (SAT) store2(a.r.q_dens, i0, qd);
-                    store2(h.q_lam, i0, qla); store2(h.q_phi, i0, qph); store2(a.r.q_rr, i0, qr);
-                    store2(h.q_kk, i0, qk); store2(h.q_ll, i0, ql); store2(a.r.q_mm, i0, qm);
+                    if (SAT) storev(a.r.q_dens, i0, qd);
+                    storev(h.q_lam, i0, qla); storev(h.q_phi, i0, qph); storev(a.r.q_rr, i0, qr);
+                    storev(h.q_kk, i0, qk); storev(h.q_ll, i0, ql); storev(a.r.q_mm, i0, qm);
                 }
             }
         }
-        deposit_tile<2, 0>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
+        deposit_tile<2, 0, double>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
                            ncp, lane, wmin, wmax, acc);
     }
     flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);

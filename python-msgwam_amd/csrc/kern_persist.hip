@@ -1,0 +1,27 @@
+// Persistent RK3 kernels of ONE ray type (MSGW_REAL = double | float) and ONE flavour (MSGW_NRES = 0: all rays
+// streamed, 4 workgroups per CU; 2: two register-resident tiles per workgroup, 2 workgroups per CU).
+#include <type_traits>
+#include "kernel_table.h"
+#include "persist_kernel.h"
+
+#if !defined(MSGW_REAL) || !defined(MSGW_NRES)
+#error "compile with -DMSGW_REAL=double|float -DMSGW_NRES=0|2"
+#endif
+
+namespace msgw {
+
+typedef MSGW_REAL real_t;
+
+template <>
+const void *persist_kernel_impl<real_t, MSGW_NRES>(bool sat, bool fvec, bool direct, bool relaunch)
+{
+    return bsel(sat, [&](auto SAT) { return bsel(fvec, [&](auto FVEC) { return bsel(direct, [&](auto DIR) {
+        return bsel(relaunch, [&](auto RL) -> const void * {
+            if constexpr (decltype(SAT)::value && decltype(DIR)::value) return nullptr;
+            else return reinterpret_cast<const void *>(
+                &k_rk3_persist<real_t, decltype(SAT)::value, decltype(FVEC)::value, decltype(DIR)::value, MSGW_NRES,
+                               decltype(RL)::value>);
+        }); }); }); });
+}
+
+}   // namespace msgw

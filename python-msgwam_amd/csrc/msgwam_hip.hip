@@ -22,6 +22,9 @@
 #include <string>
 #include <vector>
 
+#include <type_traits>
+
+#include "kernel_table.h"
 #include "column_kernels.h"
 #include "hprop_kernels.h"
 #include "persist_kernel.h"
@@ -72,14 +75,28 @@ struct RcclApi {
 
 // Head of the node-level exchange segment (POSIX shared memory, one per communicator).  The host
 // side uses the counters to agree on the outcome of the set-up; the GPUs use flags[] and rows[].
+constexpr int XCH_MAX_RANKS = 64;                               // one polling lane per rank
 struct XchHeader {
     unsigned int magic;           // written last by rank 0
     unsigned int nranks;
     unsigned int arrived[4];      // host barriers of the set-up
     unsigned int okay[4];         // ranks that reached the barrier without an error
+    unsigned long long agree_cnt[XCH_MAX_RANKS];      // per-call agreement (xch_agree_step): call counter of a rank
+    unsigned int agree_val[XCH_MAX_RANKS][2];         // ... and its vote, by parity of the counter
 };
-constexpr unsigned int XCH_MAGIC = 0x4d534758u;                 // "MSGX"
-constexpr size_t XCH_FLAGS_OFF = 4096;                          // [nranks][8] u64, one 64-byte line per rank
+static_assert(sizeof(XchHeader) <= 4096, "header page");
+struct XchPeerSlot {              // one per rank, at XCH_PEERS_OFF: what the device-resident transport needs
+    char handle[64];              // hipIpcMemHandle_t of the rank's exchange buffer
+    char pci[16];                 // PCI id of the rank's device ("dddd:bb:dd"): ranks that share a device
+    unsigned int has_handle;
+    unsigned int pad_[11];
+};
+static_assert(sizeof(XchPeerSlot) == 128, "slot size");
+constexpr unsigned int XCH_MAGIC = 0x4d534759u;                 // "MSGY"
+constexpr size_t XCH_PEERS_OFF = 4096;                          // [XCH_MAX_RANKS] XchPeerSlot
+constexpr size_t XCH_FLAGS_OFF = 4096 + 128 * XCH_MAX_RANKS;    // [nranks][8] u64, one 64-byte line per rank
+constexpr size_t XCH_SCRATCH_BYTES = 4096;                      // device scratch: [0..63] ints, [64..] XchArgs, [1024..] peer pointers
+constexpr size_t XCH_SCRATCH_PEERS = 1024;
 constexpr unsigned long long XCH_TIMEOUT_TICKS = 2000000000ull; // 20 s of wall clock (100 MHz): ranks start apart
 constexpr int XCH_TEST_ROUNDS = 6;
 constexpr size_t PDONE_WORDS = 128 + (size_t)2 * msgw::PERSIST_GROUPS * msgw::TICKET_STRIDE;   // counters of the persistent kernel
@@ -98,13 +115,16 @@ struct msgw_ctx {
     double bvf = 0, f0 = 0, kappa = 0;
     int sat_online = 0;
 
-    // rays
-    std::vector<double *> ray_bufs;
-    double *dens = nullptr, *rr = nullptr, *mm = nullptr, *drr = nullptr, *kk = nullptr, *ll = nullptr,
-           *dmm = nullptr, *vol = nullptr, *fray = nullptr, *pvf = nullptr, *q_rr = nullptr,
-           *q_mm = nullptr, *q_dens = nullptr, *rr0 = nullptr, *mm0 = nullptr,
-           *src_dens = nullptr, *src_rr = nullptr, *src_mm = nullptr,   // MSGW_RELAUNCH: values at upload
-           *cgbuf = nullptr;                                            // cg_rr carried between passes (persistent kernel)
+    // rays: float64 (default) or float32 (MSGW_DTYPE_F32) SoA arrays
+    int f32 = 0;
+    size_t esz = sizeof(double);     // bytes per element of the ray arrays
+    int tile = Real<double>::TILE;   // rays per workgroup iteration (16 B per lane per array)
+    std::vector<void *> ray_bufs;
+    void *dens = nullptr, *rr = nullptr, *mm = nullptr, *drr = nullptr, *kk = nullptr, *ll = nullptr,
+         *dmm = nullptr, *vol = nullptr, *fray = nullptr, *pvf = nullptr, *q_rr = nullptr,
+         *q_mm = nullptr, *q_dens = nullptr, *rr0 = nullptr, *mm0 = nullptr,
+         *src_dens = nullptr, *src_rr = nullptr, *src_mm = nullptr,   // MSGW_RELAUNCH: values at upload
+         *cgbuf = nullptr;                                            // cg_rr carried between passes (persistent kernel)
     double relaunch_frac = 1e-6;
     // HPROP_GLOBAL = True (horizontal propagation): lam, phi and their RK registers, registers of kk, ll
     int hprop = 0;
@@ -146,7 +166,10 @@ struct msgw_ctx {
     int service = 1;                 // reducer workgroups beside the workers (MSGW_SERVICE=0: last arriver reduces)
     int regtiles = 1;                // register-resident tiles in the persistent kernel (MSGW_REGTILES=0 disables)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
-    unsigned int *pdone = nullptr;   // PDONE_WORDS: [0] ready, [1] status, [32..33] done2, [64] final rows, [96] rank rows, [128..] group tickets
+    unsigned int *pdone = nullptr;   // PDONE_WORDS: [0] ready, [32..33] done2, [64] final rows, [96] rank rows, [128..] group tickets
+    int *pstatus = nullptr;          // raised by a persistent launch whose bounded wait timed out; sticky until the next
+                                     // msgw_upload_rays, read back at the next blocking call (check_status)
+    bool status_armed = false;       // a persistent launch has been enqueued since the last check
     double *flux2 = nullptr;         // [2][ncols] final flux rows of the persistent kernel
     double *shtab = nullptr;         // [2][ng-2] double4 shear tables published by the column workgroup
     unsigned long long *pstamps = nullptr;   // diagnostic builds only
@@ -175,7 +198,16 @@ struct msgw_ctx {
     int xch_stride = 0;
     unsigned long long xch_seq = 0;           // sequence number of the newest flux exchanged
     bool xch_ok = false;                      // agreed by all ranks after the self-test
-    int *xch_scratch = nullptr;               // device int: self-test result / agreement buffer
+    int *xch_scratch = nullptr;               // device scratch: self-test result / agreement buffer / XchArgs / peer pointers
+    // device-resident transport: this rank's buffer in its own HBM + the other ranks' buffers mapped through HIP IPC
+    void *xch_local = nullptr;
+    std::vector<void *> xch_peer_open;        // mappings to close
+    double *const *xch_peer_rows = nullptr;   // device arrays of the peers' row / flag pointers (in xch_scratch)
+    unsigned long long *const *xch_peer_flags = nullptr;
+    bool xch_direct = false;
+    int tenants = 1;                          // ranks of this communicator that share this rank's physical device
+    unsigned long long xch_calls = 0;         // per-call agreements done (xch_agree_step)
+    char pci_id[16] = {0};
 
     // counters / kernel timing
     msgw_counters_t cnt{};
@@ -207,18 +239,12 @@ int fail(msgw_ctx *c, int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                \
     } while (0)
 
-// the exact constant division (div_const) needs d's significand not to be all ones
-int markstein_ok(double d)
+size_t stage_lds_bytes(const msgw_ctx *c)
 {
-    uint64_t b;
-    std::memcpy(&b, &d, sizeof b);
-    return ((b & 0xFFFFFFFFFFFFFull) != 0xFFFFFFFFFFFFFull) && std::isfinite(d) && d > 0;
-}
-
-size_t stage_lds_bytes(int ng)
-{
-    const int ni = ng - 2, nc = ng - 1, ncp = ng - 2;
-    return sizeof(double) * (size_t)(5 * ni + 3 * nc + WAVES * 2 * ncp) + sizeof(int) * 2 * WAVES + 16;
+    const int ng = c->ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
+    // tables in the ray type (rounded up to 16 B), a float64 copy of grid[1:-1] for float32 rays, float64 wave rows
+    const size_t tables = ((c->esz * (size_t)(5 * ni + 3 * nc) + 15) & ~(size_t)15) + (c->f32 ? sizeof(double) * ni : 0);
+    return tables + sizeof(double) * (size_t)(WAVES * 2 * ncp) + sizeof(int) * 2 * WAVES + 16;
 }
 size_t proj_lds_bytes(int nG, int np)
 {
@@ -238,32 +264,32 @@ int pick_nseg(int ncols)
     return s < 1 ? 1 : (s > 8 ? 8 : s);
 }
 
-template <typename K>
-int ensure_lds(msgw_ctx *c, K kernel, size_t bytes)
+int ensure_lds(msgw_ctx *c, const void *kernel, size_t bytes)
 {
+    if (!kernel)
+        return fail(c, MSGW_ERR_UNSUP, "this kernel variant is not built (see kernel_table.h)");
     if (bytes > 160 * 1024)
         return fail(c, MSGW_ERR_UNSUP, "column too large for LDS staging (%zu B needed, ngrid=%d)", bytes, c->ng);
     if (bytes > 64 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        HIPCHK(c, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return MSGW_OK;
 }
 
 // Launch geometry: every workgroup owns `rays_per_block` contiguous rays, a whole number of
-// 512-ray tiles, at most ncu*blocks_per_cu workgroups.  (A finer split that balances the
-// workgroups exactly over the CUs -- 1009 x 992 rays instead of 977 x 1024 at 1e6 rays -- was
+// tiles (512 float64 / 1024 float32 rays), at most ncu*blocks_per_cu workgroups.  (A finer split that
+// balances the workgroups exactly over the CUs -- 1009 x 992 rays instead of 977 x 1024 at 1e6 rays -- was
 // measured: no gain for the per-stage kernels, 4 % slower for the persistent kernel, whose
 // synchronisation cost grows with the number of workgroups.)
 void geometry(msgw_ctx *c, int64_t n)
 {
-    const int64_t ntiles = (n + TILE - 1) / TILE;
+    const int64_t ntiles = (n + c->tile - 1) / c->tile;
     const int64_t maxb = (int64_t)c->ncu * c->blocks_per_cu;
     int64_t tpb = (ntiles + maxb - 1) / maxb;
     if (tpb < 1) tpb = 1;
     int64_t blocks = (ntiles + tpb - 1) / tpb;
     if (blocks < 1) blocks = 1;
     c->tiles_per_block = (int)tpb;
-    c->rays_per_block = tpb * TILE;
+    c->rays_per_block = tpb * c->tile;
     c->blocks = (int)blocks;
 }
 
@@ -337,11 +363,77 @@ int ensure_groups(msgw_ctx *c)
         HIPCHK(c, hipMalloc(&c->grp_cnt, sizeof(unsigned int) * 64));
         HIPCHK(c, hipMalloc(&c->grp_rows2, sizeof(double) * (size_t)2 * PERSIST_GROUPS * 2 * (c->ng - 2)));
         HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * PDONE_WORDS));
+        HIPCHK(c, hipMalloc(&c->pstatus, 128));
+        HIPCHK(c, hipMemsetAsync(c->pstatus, 0, 128, c->stream));
         HIPCHK(c, hipMalloc(&c->flux2, sizeof(double) * (size_t)4 * 2 * (c->ng - 2)));   // [2] final + [2] this rank's
         HIPCHK(c, hipMalloc(&c->shtab, sizeof(double) * (size_t)2 * 4 * (c->ng - 2)));
     }
     HIPCHK(c, hipMemsetAsync(c->grp_cnt, 0, sizeof(unsigned int) * 64, c->stream));
     return MSGW_OK;
+}
+
+hipEvent_t *timing_events(msgw_ctx *c)
+{
+    if (c->kev_used + 2 > c->kev.size()) {
+        const size_t old = c->kev.size();
+        c->kev.resize(old + 512);
+        for (size_t i = old; i < c->kev.size(); ++i)
+            if (hipEventCreate(&c->kev[i]) != hipSuccess) { c->kev.resize(i); return nullptr; }
+    }
+    hipEvent_t *p = &c->kev[c->kev_used];
+    c->kev_used += 2;
+    return p;
+}
+
+// ---- kernel dispatch --------------------------------------------------------
+// Kernels live in other translation units (kernel_table.h) and are launched through their entry point.
+// Ray kernels go through hipExtLaunchKernel so that, when asked, a pair of events receives the kernel's
+// own begin/end timestamps (no launch gap in the interval).
+template <typename Args>
+int launch_struct(msgw_ctx *c, const void *fn, unsigned grid, unsigned block, size_t lds, const Args &a,
+                  hipStream_t stream = nullptr, bool timed = false)
+{
+    if (int rc = ensure_lds(c, fn, lds)) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        hipEvent_t *ev = timing_events(c);
+        if (ev) { e0 = ev[0]; e1 = ev[1]; }
+    }
+    void *args[] = {const_cast<Args *>(&a)};
+    HIPCHK(c, hipExtLaunchKernel(fn, dim3(grid), dim3(block), args, lds, stream ? stream : c->stream, e0, e1, 0));
+    return MSGW_OK;
+}
+// kernels with a plain parameter list; the argument types must be the kernel's parameter types exactly
+template <typename... A>
+int launch_list(msgw_ctx *c, const void *fn, unsigned grid, unsigned block, A... a)
+{
+    if (!fn) return fail(c, MSGW_ERR_UNSUP, "this kernel variant is not built (see kernel_table.h)");
+    void *args[] = {(void *)&a...};
+    HIPCHK(c, hipLaunchKernel(fn, dim3(grid), dim3(block), args, 0, c->stream));
+    return MSGW_OK;
+}
+
+template <typename T>
+RayPtrsT<T> ray_ptrs(const msgw_ctx *c)
+{
+    auto p = [](void *v) { return static_cast<T *>(v); };
+    return RayPtrsT<T>{p(c->dens), p(c->rr), p(c->mm), p(c->drr), p(c->kk), p(c->ll), p(c->dmm), p(c->vol), p(c->fray),
+                       p(c->pvf), p(c->q_rr), p(c->q_mm), p(c->q_dens), p(c->rr0), p(c->mm0), p(c->src_dens),
+                       p(c->src_rr), p(c->src_mm), p(c->cgbuf)};
+}
+
+// the exact constant division (div_const) needs d's significand not to be all ones
+int markstein_ok(double d)
+{
+    uint64_t b;
+    std::memcpy(&b, &d, sizeof b);
+    return ((b & 0xFFFFFFFFFFFFFull) != 0xFFFFFFFFFFFFFull) && std::isfinite(d) && d > 0;
+}
+int markstein_ok(float d)
+{
+    uint32_t b;
+    std::memcpy(&b, &d, sizeof b);
+    return ((b & 0x7FFFFFu) != 0x7FFFFFu) && std::isfinite(d) && d > 0;
 }
 
 // First level of the flux reduction (many workgroup rows -> RED1_GROUPS dense rows);
@@ -355,37 +447,36 @@ int reduce_level1(msgw_ctx *c, ColArgs &a, bool force = false)
     r.partial = a.partial; r.ranges = a.ranges; r.out = c->row2;
     const int rows_per_group = (a.nblocks + RED1_GROUPS - 1) / RED1_GROUPS + 1;
     const size_t lds = sizeof(double) * (size_t)r.nseg * r.ncols + sizeof(int) * 2 * (size_t)rows_per_group + 16;
-    if (int rc = ensure_lds(c, k_flux_reduce1, lds)) return rc;
     const int groups = a.nblocks < RED1_GROUPS ? a.nblocks : RED1_GROUPS;
-    hipLaunchKernelGGL(k_flux_reduce1, dim3(groups), dim3(COL_BLOCK), lds, c->stream, r);
-    HIPCHK(c, hipGetLastError());
+    if (int rc = launch_struct(c, flux_reduce1_kernel(), groups, COL_BLOCK, lds, r)) return rc;
     a.partial = c->row2; a.ranges = nullptr; a.nblocks = groups;
     return MSGW_OK;
 }
 
-StageArgs make_stage_args(msgw_ctx *c, double dt, unsigned flags)
+template <typename T>
+StageArgsT<T> make_stage_args(msgw_ctx *c, double dt, unsigned flags)
 {
-    StageArgs a{};
+    StageArgsT<T> a{};
     a.n = c->n;
     a.ng = c->ng;
     a.tiles_per_block = c->tiles_per_block;
     a.rays_per_block = c->rays_per_block;
-    a.dt = dt;
-    a.bvf2 = std::pow(c->bvf, 2.0);               // python `bvf ** 2` (lib/libprop.py:383)
-    a.f_uni = c->f_uni;
-    a.f0sq = std::pow(c->f0, 2.0);                // python `ff ** 2` with scalar ff (:601)
-    a.same_f = (!c->fvec && (c->f_uni * c->f_uni == a.f0sq)) ? 1 : 0;
-    a.sat_c = std::pow(c->kappa, 2.0) * .5;       // `kappa**2 * .5` (:601)
-    a.sat_rr_div = (flags & MSGW_DIRECT_SAT_QUIRK) ? 1.0 : dt;
-    a.xg0 = c->xg0; a.inv_dzg = 1.0 / c->dzg;
-    a.gs0 = c->gs0; a.inv_dzs = 1.0 / c->dzs;
-    a.xg_last = c->xg_last; a.gs_last = c->gs_last;
-    a.dzs = c->dzs;
-    a.mk_ok = markstein_ok(c->dzs);
-    a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
-                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0, c->src_dens, c->src_rr, c->src_mm, c->cgbuf};
+    a.dt = (T)dt;
+    a.dtc = dt;
+    a.bvf2 = (T)std::pow(c->bvf, 2.0);            // python `bvf ** 2` (lib/libprop.py:383)
+    a.f_uni = (T)c->f_uni;
+    a.f0sq = (T)std::pow(c->f0, 2.0);             // python `ff ** 2` with scalar ff (:601)
+    a.same_f = (!c->fvec && (a.f_uni * a.f_uni == a.f0sq)) ? 1 : 0;
+    a.sat_c = (T)(std::pow(c->kappa, 2.0) * .5);  // `kappa**2 * .5` (:601)
+    a.sat_rr_div = (flags & MSGW_DIRECT_SAT_QUIRK) ? T(1) : (T)dt;
+    a.xg0 = (T)c->xg0; a.inv_dzg = (T)(1.0 / c->dzg);
+    a.gs0 = (T)c->gs0; a.inv_dzs = T(1) / (T)c->dzs;
+    a.xg_last = (T)c->xg_last; a.gs_last = (T)c->gs_last;
+    a.dzs = (T)c->dzs;
+    a.mk_ok = markstein_ok(a.dzs);
+    a.r = ray_ptrs<T>(c);
     a.relaunch = (flags & MSGW_RELAUNCH) ? 1 : 0;
-    a.z_bot = c->z_bot; a.z_top = c->z_top; a.relaunch_frac = c->relaunch_frac;
+    a.z_bot = (T)c->z_bot; a.z_top = (T)c->z_top; a.relaunch_frac = (T)c->relaunch_frac;
     a.c = ColPtrs{c->grid + 1, c->dudz, c->dvdz, c->slu, c->slv, c->grids, c->rhobar, c->slrho};
     a.partial = c->partial;
     a.ranges = c->ranges;
@@ -417,107 +508,39 @@ ColArgs make_col_args(msgw_ctx *c, double dt, unsigned flags)
     return a;
 }
 
-hipEvent_t *timing_events(msgw_ctx *c)
+// mode: 0 plain, 1 online saturation, 2 direct (driver) saturation.  The relaunch extension is a compile-time
+// variant of stage 2 only, so that the default kernels carry none of its registers.
+template <typename T>
+int launch_stage(msgw_ctx *c, int stage, const StageArgsT<T> &a, int mode, bool timed)
 {
-    if (c->kev_used + 2 > c->kev.size()) {
-        const size_t old = c->kev.size();
-        c->kev.resize(old + 512);
-        for (size_t i = old; i < c->kev.size(); ++i)
-            if (hipEventCreate(&c->kev[i]) != hipSuccess) { c->kev.resize(i); return nullptr; }
-    }
-    hipEvent_t *p = &c->kev[c->kev_used];
-    c->kev_used += 2;
-    return p;
+    const bool sat = mode == 1, direct = mode == 2 && stage != 1, rl = stage == 2 && a.relaunch;
+    int form = FORM_PLAIN;
+    if (c->ng - 2 > 128) form = FORM_TALL;             // tall columns: per-level sums stay in LDS (NH = 0)
+    else if (c->lagchain) form = FORM_LAG;             // lagged chain: deposit of the produced state, group rows by parity
+    else if (c->groupred) form = FORM_GROUP;           // fused chain: first-level flux reduction inside the kernel
+    return launch_struct(c, stage_kernel<T>(stage, sat, c->fvec, true, direct, form, rl), c->blocks, BLOCK,
+                         stage_lds_bytes(c), a, nullptr, timed);
 }
 
-// ---- kernel dispatch --------------------------------------------------------
-// Ray kernels are launched through hipExtLaunchKernelGGL so that, when asked, a pair of
-// events receives the kernel's own begin/end timestamps (no launch gap in the interval).
-template <typename K>
-int launch_ray_kernel(msgw_ctx *c, K k, size_t lds, const StageArgs &a)
+template <typename T>
+int launch_probe(msgw_ctx *c, const StageArgsT<T> &a, bool sat, bool deposit)
 {
-    if (int rc = ensure_lds(c, k, lds)) return rc;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->time_next) {
-        hipEvent_t *ev = timing_events(c);
-        if (ev) { e0 = ev[0]; e1 = ev[1]; }
-    }
-    hipExtLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, e0, e1, 0, a);
-    HIPCHK(c, hipGetLastError());
-    return MSGW_OK;
+    const int form = (c->ng - 2 > 128) ? FORM_TALL : FORM_PLAIN;
+    return launch_struct(c, stage_kernel<T>(3, sat, c->fvec, deposit, false, form, false), c->blocks, BLOCK,
+                         stage_lds_bytes(c), a);
 }
 
-// RL: the MSGW_RELAUNCH extension (stage 2 only; a compile-time variant so that the default kernels carry
-// none of its registers)
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool RL = false>
-int launch_stage_t(msgw_ctx *c, const StageArgs &a)
+template <typename T>
+int launch_fixed(msgw_ctx *c, const StageArgsT<T> &a, int mode, bool timed)
 {
-    constexpr bool GR = DEPOSIT && STAGE != 3;
-    if (c->ng - 2 > 128)   // tall columns: per-level sums stay in LDS (NH = 0)
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 0, false, false, RL>, stage_lds_bytes(c->ng), a);
-    if (c->lagchain && DEPOSIT && STAGE != 3)   // lagged chain: deposit of the produced state, group rows by parity
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, GR, GR, RL>, stage_lds_bytes(c->ng), a);
-    if (c->groupred && DEPOSIT && STAGE != 3)   // fused chain: first-level flux reduction inside the kernel
-        return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, GR, false, RL>, stage_lds_bytes(c->ng), a);
-    return launch_ray_kernel(c, k_ray_stage<STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, false, false, RL>, stage_lds_bytes(c->ng), a);
+    return launch_struct(c, fixed_kernel<T>(mode == 1, c->fvec, mode == 2), c->blocks, BLOCK, stage_lds_bytes(c), a,
+                         nullptr, timed);
 }
 
-// mode: 0 plain, 1 online saturation, 2 direct (driver) saturation
-template <int STAGE>
-int launch_stage(msgw_ctx *c, const StageArgs &a, int mode)
-{
-    const bool fv = c->fvec;
-    if (STAGE == 2 && a.relaunch) {                            // extension: recycle rays after the step's last stage
-        if (mode == 1) return fv ? launch_stage_t<2, true, true, true, false, true>(c, a)
-                                 : launch_stage_t<2, true, false, true, false, true>(c, a);
-        if (mode == 2) return fv ? launch_stage_t<2, false, true, true, true, true>(c, a)
-                                 : launch_stage_t<2, false, false, true, true, true>(c, a);
-        return fv ? launch_stage_t<2, false, true, true, false, true>(c, a)
-                  : launch_stage_t<2, false, false, true, false, true>(c, a);
-    }
-    if (mode == 1) return fv ? launch_stage_t<STAGE, true, true, true, false>(c, a)
-                             : launch_stage_t<STAGE, true, false, true, false>(c, a);
-    if (mode == 2 && STAGE != 1) return fv ? launch_stage_t<STAGE, false, true, true, true>(c, a)
-                                           : launch_stage_t<STAGE, false, false, true, true>(c, a);
-    return fv ? launch_stage_t<STAGE, false, true, true, false>(c, a)
-              : launch_stage_t<STAGE, false, false, true, false>(c, a);
-}
-
-int launch_probe(msgw_ctx *c, const StageArgs &a, bool sat, bool deposit)
-{
-    const bool fv = c->fvec;
-#define P_(S, F, D) launch_stage_t<3, S, F, D, false>(c, a)
-    if (sat) {
-        if (fv) return deposit ? P_(true, true, true) : P_(true, true, false);
-        return deposit ? P_(true, false, true) : P_(true, false, false);
-    }
-    if (fv) return deposit ? P_(false, true, true) : P_(false, true, false);
-    return deposit ? P_(false, false, true) : P_(false, false, false);
-#undef P_
-}
-
-template <bool SAT, bool FVEC, bool DIRECT>
-int launch_fixed_t(msgw_ctx *c, const StageArgs &a)
-{
-    return launch_ray_kernel(c, k_ray_step_fixed<SAT, FVEC, DIRECT>, stage_lds_bytes(c->ng), a);
-}
-int launch_fixed(msgw_ctx *c, const StageArgs &a, int mode)
-{
-    const bool fv = c->fvec;
-    if (mode == 1) return fv ? launch_fixed_t<true, true, false>(c, a) : launch_fixed_t<true, false, false>(c, a);
-    if (mode == 2) return fv ? launch_fixed_t<false, true, true>(c, a) : launch_fixed_t<false, false, true>(c, a);
-    return fv ? launch_fixed_t<false, true, false>(c, a) : launch_fixed_t<false, false, false>(c, a);
-}
-
-template <int STAGE, int MODE>
-int launch_column_t(msgw_ctx *c, const ColArgs &a, hipStream_t stream = nullptr)
+int launch_column(msgw_ctx *c, int stage, int mode, const ColArgs &a, hipStream_t stream = nullptr)
 {
     const size_t lds = col_lds_bytes(a.ng, a.nseg, a.npay * a.ncp, a.nblocks);
-    auto k = k_column<STAGE, MODE>;
-    if (int rc = ensure_lds(c, k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(1), dim3(COL_BLOCK), lds, stream ? stream : c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    return MSGW_OK;
+    return launch_struct(c, column_kernel(stage, mode), 1, COL_BLOCK, lds, a, stream);
 }
 
 int allreduce_flux(msgw_ctx *c, double *buf = nullptr, hipStream_t stream = nullptr)
@@ -535,93 +558,150 @@ int allreduce_flux(msgw_ctx *c, double *buf = nullptr, hipStream_t stream = null
 }
 
 // flux finalise (+ all-reduce over the ranks) + mean-flow RK stage
-template <int STAGE>
-int column_stage(msgw_ctx *c, const ColArgs &a0)
+int column_stage(msgw_ctx *c, int stage, const ColArgs &a0)
 {
     ColArgs a = a0;
     if (int rc = reduce_level1(c, a)) return rc;
     if (c->nranks > 1 || (c->force_coll && c->comm)) {
-        if (int rc = launch_column_t<STAGE, COL_REDUCE>(c, a)) return rc;
+        if (int rc = launch_column(c, stage, COL_REDUCE, a)) return rc;
         if (int rc = allreduce_flux(c)) return rc;
-        return launch_column_t<STAGE, COL_UPDATE>(c, a);
+        return launch_column(c, stage, COL_UPDATE, a);
     }
-    return launch_column_t<STAGE, COL_REDUCE | COL_UPDATE>(c, a);
+    return launch_column(c, stage, COL_REDUCE | COL_UPDATE, a);
 }
 
-size_t persist_lds_bytes(int ng)
+size_t persist_lds_bytes(const msgw_ctx *c)
 {
-    return stage_lds_bytes(ng) + sizeof(double) * (size_t)7 * (ng - 1) + 32;
+    // + column replica (7 x (ng-1) float64) + flags; float32 rays: + the float64 shear table of the column arithmetic
+    return stage_lds_bytes(c) + sizeof(double) * (size_t)7 * (c->ng - 1) + 32 +
+           (c->f32 ? sizeof(double) * 4 * (size_t)(c->ng - 2) + 32 : 0);
 }
 
-template <bool SAT, bool FVEC, bool DIRECT, int NRES>
-int launch_persist_t(msgw_ctx *c, PersistArgs &pa, bool *resident)
+// A raised status word means a bounded wait of a persistent launch timed out (a workgroup was not resident, the GPU
+// is shared, or a rank died): the step was abandoned half-way and the ray state is invalid.  The launch itself is not
+// waited for (calls are stream-ordered); the word is read at the next blocking call.
+int check_status(msgw_ctx *c)
 {
-    auto k = k_rk3_persist<SAT, FVEC, DIRECT, NRES>;
-    const size_t lds = persist_lds_bytes(c->ng);
-    if (int rc = ensure_lds(c, k, lds)) return rc;
+    if (!c->status_armed || !c->pstatus) return MSGW_OK;
+    int status = 0;
+    HIPCHK(c, hipMemcpyAsync(&status, c->pstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->status_armed = false;
+    if (status == 0) return MSGW_OK;
+    c->persist = 0;                                            // the per-stage kernels are used from now on
+    c->have_rays = false;
+    if (c->nranks > 1 || c->force_coll)
+        return fail(c, MSGW_ERR_HIP, "persistent RK3 kernel timed out in the node-level flux exchange (a rank "
+                    "died, or the ranks did not call msgw_step alike); state is invalid, upload the rays again");
+    return fail(c, MSGW_ERR_HIP, "persistent RK3 kernel timed out waiting for other workgroups "
+                "(not all of them resident: is the GPU shared?); state is invalid, upload the rays again "
+                "(the per-stage kernels will be used from now on)");
+}
+
+// Geometry of one persistent launch (nres: register-resident tiles per workgroup).  *fits = false when this
+// flavour does not apply to the resident rays (then nothing is changed).
+struct PersistPlan {
+    int nres = 0, blocks = 0, tiles_per_block = 0, grp_size = 1, ngroups = 1, nservice = 0, grid = 0;
+    int64_t rays_per_block = 0;
+    const void *fn = nullptr;
+    size_t lds = 0;
+};
+template <typename T>
+int plan_persist(msgw_ctx *c, int nres, int mode, bool rl, bool multi, PersistPlan &pl, bool *fits)
+{
+    *fits = false;
+    pl = PersistPlan{};
+    pl.nres = nres;
+    pl.fn = persist_kernel<T>(mode == 1, c->fvec, mode == 2, nres, rl);
+    pl.lds = persist_lds_bytes(c);
+    if (int rc = ensure_lds(c, pl.fn, pl.lds)) return rc;
     int per_cu = 0;
-    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, BLOCK, lds));
-    const long long slots = (long long)per_cu * c->ncu;
+    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pl.fn, BLOCK, pl.lds));
+    // all workgroups of the grid must be co-resident.  The occupancy query is the device's capacity for THIS
+    // process; ranks that share one device (rehearsals on a 1-GPU box) split it evenly (c->tenants, agreed on
+    // when the communicator was set up).  A foreign tenant cannot be seen: the bounded waits turn that case
+    // into an error instead of a hang.
+    const long long slots = (long long)per_cu * c->ncu / (c->tenants > 1 ? c->tenants : 1);
     int blocks = c->blocks;
-    if (NRES > 0) {
+    pl.tiles_per_block = c->tiles_per_block;
+    pl.rays_per_block = c->rays_per_block;
+    if (nres > 0) {
         // own geometry: as many ray workgroups as fit beside 16 reducers, the column and the exchange
         // workgroup at this kernel's occupancy (2 per CU)
-        const long long ntiles = (c->n + TILE - 1) / TILE;
+        const long long ntiles = (c->n + c->tile - 1) / c->tile;
         const long long maxb = slots - (16 + 2);
-        if (maxb < 1) { *resident = false; return MSGW_OK; }
+        if (maxb < 1) return MSGW_OK;
         const long long tpb = std::max<long long>((ntiles + maxb - 1) / maxb, 1);
         // measured with 2 resident tiles: +10 % at 2e6 rays (8 tiles per workgroup), +3 % at 4e6 and 8e6 (16, 32),
         // -10 % at 16e6 (64), where 4 workgroups per CU with all rays streamed are better
-        if (tpb > 16 * NRES) { *resident = false; return MSGW_OK; }
+        if (tpb > 16 * nres) return MSGW_OK;
         blocks = (int)((ntiles + tpb - 1) / tpb);
-        pa.s.tiles_per_block = (int)tpb;
-        pa.s.rays_per_block = tpb * TILE;
-        pa.nworkers = blocks;
+        pl.tiles_per_block = (int)tpb;
+        pl.rays_per_block = tpb * c->tile;
     }
-    const int max_groups = NRES > 0 ? 16 : PERSIST_GROUPS;
-    pa.s.grp_size = (blocks + max_groups - 1) / max_groups;
-    pa.ngroups = (blocks + pa.s.grp_size - 1) / pa.s.grp_size;
+    pl.blocks = blocks;
+    const int max_groups = nres > 0 ? 16 : PERSIST_GROUPS;
+    pl.grp_size = (blocks + max_groups - 1) / max_groups;
+    pl.ngroups = (blocks + pl.grp_size - 1) / pl.grp_size;
     // reducer workgroups (one per group) + the column workgroup when they fit beside the ray workgroups,
     // else the last arriver reduces
-    pa.nservice = (c->service && blocks + pa.ngroups + 1 + (pa.xch ? 1 : 0) <= slots) ? pa.ngroups : 0;
-    pa.opts = pa.nservice ? 0u : PERSIST_OPT_PRIO;
-    if (const char *e = std::getenv("MSGW_PRIO")) pa.opts = std::atoi(e) ? PERSIST_OPT_PRIO : 0u;
+    pl.nservice = (c->service && blocks + pl.ngroups + 1 + (multi ? 1 : 0) <= slots) ? pl.ngroups : 0;
     // + reducer workgroups + the column workgroup + the exchange workgroup
-    const int grid = blocks + pa.nservice + (pa.nservice ? 1 : 0) + (pa.xch ? 1 : 0);
-    *resident = slots >= grid && grid <= 2048;                 // every workgroup co-resident
-    if (!*resident) return MSGW_OK;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->time_next) {
-        hipEvent_t *ev = timing_events(c);
-        if (ev) { e0 = ev[0]; e1 = ev[1]; }
-    }
-    hipExtLaunchKernelGGL(k, dim3(grid), dim3(BLOCK), lds, c->stream, e0, e1, 0, pa);
-    HIPCHK(c, hipGetLastError());
-    c->cnt.persist_resident_tiles = NRES;
+    pl.grid = blocks + pl.nservice + (pl.nservice ? 1 : 0) + (multi ? 1 : 0);
+    *fits = slots >= pl.grid && pl.grid <= 2048;               // every workgroup co-resident
     return MSGW_OK;
 }
 
+bool xch_agree_step(msgw_ctx *c, bool mine, bool *all);
+
 // All `count` steps in ONE persistent launch.  *used = false when the path does not apply
 // (then nothing was enqueued and the caller takes the per-stage path).
+template <typename T>
 int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_kernels, bool *used)
 {
     *used = false;
     const bool can_fuse = (2 * (c->ng - 2) <= BLOCK) && (c->ng - 1 <= BLOCK);
     const bool multi = c->nranks > 1 || c->force_coll;
-    if (!c->persist || !can_fuse || (multi && !c->xch_ok) || (flags & (MSGW_FIXED_BACKGROUND | MSGW_RELAUNCH)) || count <= 0)
-        return MSGW_OK;                                        // (the relaunch extension lives in the per-stage kernels)
+    if ((flags & MSGW_FIXED_BACKGROUND) || count <= 0) return MSGW_OK;
     const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
-    PersistArgs pa{};
-    pa.s = make_stage_args(c, dt, flags);
+    const bool rl = (flags & MSGW_RELAUNCH) != 0;
+    bool want = c->persist && can_fuse && (!multi || c->xch_ok);
+    PersistPlan pl;
+    bool fits = false;
+    if (want && c->regtiles)                                   // first choice: register-resident tiles
+        if (int rc = plan_persist<T>(c, 2, mode, rl, multi, pl, &fits)) return rc;
+    if (want && !fits)
+        if (int rc = plan_persist<T>(c, 0, mode, rl, multi, pl, &fits)) return rc;
+    want = want && fits;
+    // several ranks: either every rank launches the persistent kernel or none does (a rank that declined while
+    // its peers spin in the exchange would leave them to their time-out)
+    if (multi && c->nranks > 1 && c->xch_ok) {
+        bool all = false;
+        if (!xch_agree_step(c, want, &all))
+            return fail(c, MSGW_ERR_HIP, "the ranks did not agree on the kernel path within the time limit (a rank "
+                        "died, or the ranks did not call msgw_step alike)");
+        want = all;
+    }
+    if (!want) return MSGW_OK;                                 // per-stage path
+
+    PersistArgsT<T> pa{};
+    pa.s = make_stage_args<T>(c, dt, flags);
+    pa.s.tiles_per_block = pl.tiles_per_block;
+    pa.s.rays_per_block = pl.rays_per_block;
+    pa.s.grp_size = pl.grp_size;
     pa.nsteps = count;
+    pa.ngroups = pl.ngroups;
+    pa.nworkers = pl.blocks;
+    pa.nservice = pl.nservice;
+    pa.opts = pl.nservice ? 0u : PERSIST_OPT_PRIO;
+    if (const char *e = std::getenv("MSGW_PRIO")) pa.opts = std::atoi(e) ? PERSIST_OPT_PRIO : 0u;
     pa.grp_rows2 = c->grp_rows2;
     pa.grp_part2 = c->grp_part2;
     pa.flux2 = c->flux2;
     pa.shtab = c->shtab;
     pa.ready = c->pdone;
-    pa.status = reinterpret_cast<int *>(c->pdone + 1);
+    pa.status = c->pstatus;
     pa.done2 = c->pdone + 32;
-    pa.nworkers = c->blocks;
     pa.grp_cnt2 = c->pdone + 128;
 #ifdef MSGW_STAMP
     if (!c->pstamps) HIPCHK(c, hipMalloc(&c->pstamps, sizeof(unsigned long long) * 4096 * PSTAMP_PASSES * 4));
@@ -629,59 +709,27 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.pstamps = c->pstamps;
 #endif
     pa.timeout_ticks = 20000000ull;                            // 0.2 s of wall clock per wait
-    XchArgs x{};                                               // lives until the stream is synchronised below
     if (multi) {                                               // the other ranks' launches may start much later
+        XchArgs x{};
         x.nranks = c->nranks; x.rank = c->rank; x.stride = c->xch_stride;
         x.rows = c->xch_rows; x.flags = c->xch_flags; x.seq = c->xch_seq;
+        x.direct = c->xch_direct ? 1 : 0;
+        x.peer_rows = c->xch_peer_rows; x.peer_flags = c->xch_peer_flags;
         x.timeout_ticks = XCH_TIMEOUT_TICKS;
-        XchArgs *dx = reinterpret_cast<XchArgs *>(c->xch_scratch + 16);
-        HIPCHK(c, hipMemcpyAsync(dx, &x, sizeof x, hipMemcpyHostToDevice, c->stream));
-        pa.xch = dx;
+        pa.xch = x;
+        pa.has_xch = 1;
         pa.timeout_ticks = XCH_TIMEOUT_TICKS + 100000000ull;
     }
     pa.cin = ColIn{c->uu, c->vv, c->q_uu, c->q_vv};
     pa.cout = ColOut{c->uu, c->vv, c->q_uu, c->q_vv};
     pa.dudz = c->dudz; pa.dvdz = c->dvdz; pa.slu = c->slu; pa.slv = c->slv;
     HIPCHK(c, hipMemsetAsync(c->pdone, 0, sizeof(unsigned int) * PDONE_WORDS, c->stream));
-    bool resident = false;
-    c->time_next = time_kernels;
-    int rc = MSGW_OK;
-    const bool fv = c->fvec;
-    c->cnt.persist_resident_tiles = 0;
-    // first choice: register-resident tiles (declines for ray counts where they do not pay)
-    if (c->regtiles) {
-        if (mode == 1) rc = fv ? launch_persist_t<true, true, false, 2>(c, pa, &resident) : launch_persist_t<true, false, false, 2>(c, pa, &resident);
-        else if (mode == 2) rc = fv ? launch_persist_t<false, true, true, 2>(c, pa, &resident) : launch_persist_t<false, false, true, 2>(c, pa, &resident);
-        else rc = fv ? launch_persist_t<false, true, false, 2>(c, pa, &resident) : launch_persist_t<false, false, false, 2>(c, pa, &resident);
-    }
-    if (rc == MSGW_OK && !resident) {
-        const StageArgs sa0 = make_stage_args(c, dt, flags);
-        pa.s.tiles_per_block = sa0.tiles_per_block; pa.s.rays_per_block = sa0.rays_per_block; pa.nworkers = c->blocks;
-        if (mode == 1) rc = fv ? launch_persist_t<true, true, false, 0>(c, pa, &resident) : launch_persist_t<true, false, false, 0>(c, pa, &resident);
-        else if (mode == 2) rc = fv ? launch_persist_t<false, true, true, 0>(c, pa, &resident) : launch_persist_t<false, false, true, 0>(c, pa, &resident);
-        else rc = fv ? launch_persist_t<false, true, false, 0>(c, pa, &resident) : launch_persist_t<false, false, false, 0>(c, pa, &resident);
-    }
-    c->time_next = false;
-    if (rc) return rc;
-    if (!resident) return MSGW_OK;                             // grid larger than residency: per-stage path
+    if (int rc = launch_struct(c, pl.fn, pl.grid, BLOCK, pl.lds, pa, nullptr, time_kernels)) return rc;
     *used = true;
+    c->status_armed = true;
+    c->cnt.persist_resident_tiles = pl.nres;
     c->cnt.persist_steps = count;
     if (multi) c->xch_seq += 3ull * (unsigned long long)count + 1ull;   // fluxes 0 .. 3*count were exchanged
-    // the waits are bounded; a raised status means a workgroup was not resident (or the GPU is
-    // shared): report it loudly, never spin forever
-    int status = 0;
-    HIPCHK(c, hipMemcpyAsync(&status, c->pdone + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (status != 0) {
-        c->persist = 0;
-        c->have_rays = false;                                  // the step was abandoned half-way
-        if (multi)
-            return fail(c, MSGW_ERR_HIP, "persistent RK3 kernel timed out in the node-level flux exchange (a rank "
-                        "died, or the ranks did not call msgw_step alike); state is invalid");
-        return fail(c, MSGW_ERR_HIP, "persistent RK3 kernel timed out waiting for other workgroups "
-                    "(not all of them resident?); state is invalid, upload the rays again "
-                    "(the per-stage kernels will be used from now on)");
-    }
     return MSGW_OK;
 }
 
@@ -692,10 +740,17 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
 // k_ray_stage<LAG> -> record;  on stream B:  wait(row of F_{q+1}) ->
 // ncclAllReduce -> record (the ray-stage kernel itself reduces its rows to one row).  Group rows and
 // flux rows are double-buffered by flux parity.
+template <typename T>
 int enqueue_steps_lagged(msgw_ctx *c, double dt, unsigned flags, int count, bool time_kernels)
 {
     const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
     const int ncols = 2 * (c->ng - 2);
+    // several ranks must sum their rows: without a communicator (MSGW_EXCHANGE_ONLY=1) only the persistent kernel
+    // can do that, and it has declined this step (relaunch off its fast path, MSGW_PERSIST=0, a grid that is not
+    // co-resident ...): every rank would silently advance its column with its local flux only
+    if (c->nranks > 1 && !c->comm)
+        return fail(c, MSGW_ERR_RCCL, "this multi-rank step cannot take the persistent kernel and needs the RCCL "
+                    "all-reduce chain, but the communicator was set up without RCCL (MSGW_EXCHANGE_ONLY=1)");
     if (!c->stream2) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
@@ -703,7 +758,7 @@ int enqueue_steps_lagged(msgw_ctx *c, double dt, unsigned flags, int count, bool
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_flux[i], hipEventDisableTiming));
         }
     }
-    StageArgs sa = make_stage_args(c, dt, flags);
+    StageArgsT<T> sa = make_stage_args<T>(c, dt, flags);
     double *rows_par[2] = {c->grp_rows, c->grp_rows + (size_t)FUSE_ROWS * ncols};
     double *flux_par[2] = {c->flux2, c->flux2 + ncols};
     const ColIn in_set[2] = {ColIn{c->uu, c->vv, c->q_uu, c->q_vv}, ColIn{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
@@ -718,15 +773,12 @@ int enqueue_steps_lagged(msgw_ctx *c, double dt, unsigned flags, int count, bool
         return MSGW_OK;
     };
     c->lagchain = true;
-    struct Guard { msgw_ctx *c; ~Guard() { c->lagchain = false; c->time_next = false; } } guard{c};
+    struct Guard { msgw_ctx *c; ~Guard() { c->lagchain = false; } } guard{c};
     // pre-pass: F_0
     sa.grp_rows = rows_par[0];
     sa.flux_out = flux_par[0];
-    {
-        const size_t lds = stage_lds_bytes(c->ng);
-        if (c->fvec) { if (int rc = launch_ray_kernel(c, k_deposit_only<true>, lds, sa)) return rc; }
-        else { if (int rc = launch_ray_kernel(c, k_deposit_only<false>, lds, sa)) return rc; }
-    }
+    if (int rc = launch_struct(c, deposit_only_kernel<T>(c->fvec), c->blocks, BLOCK, stage_lds_bytes(c), sa, nullptr, time_kernels))
+        return rc;
     HIPCHK(c, hipEventRecord(c->ev_rows[0], c->stream));
     if (int rc = reduce_on_b(0)) return rc;
     int cur = 0;
@@ -741,13 +793,7 @@ int enqueue_steps_lagged(msgw_ctx *c, double dt, unsigned flags, int count, bool
         sa.grp_rows = rows_par[(q + 1) & 1];             // this pass publishes F_{q+1} ...
         sa.flux_out = flux_par[(q + 1) & 1];             // ... reduced in-kernel to one row
         if (q >= 1) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_flux[(q - 1) & 1], 0));
-        c->time_next = time_kernels;
-        int rc = MSGW_OK;
-        if (s == 0) rc = launch_stage<0>(c, sa, mode);
-        else if (s == 1) rc = launch_stage<1>(c, sa, mode);
-        else rc = launch_stage<2>(c, sa, mode);
-        c->time_next = false;
-        if (rc) return rc;
+        if (int rc = launch_stage<T>(c, s, sa, mode, time_kernels)) return rc;
         if (q >= 1) cur ^= 1;
         HIPCHK(c, hipEventRecord(c->ev_rows[(q + 1) & 1], c->stream));
         if (q + 1 <= npass - 1)                          // F_{q+1} is consumed by pass q+2 <= npass (the final update)
@@ -759,7 +805,7 @@ int enqueue_steps_lagged(msgw_ctx *c, double dt, unsigned flags, int count, bool
     fin.flux = flux_par[(npass - 1) & 1];
     fin.in = in_set[cur];
     fin.out = out_set[0];
-    return launch_column_t<2, COL_UPDATE>(c, fin);
+    return launch_column(c, 2, COL_UPDATE, fin);
 }
 
 // Enqueue `count` RK3 steps (lib/libprop.py:693-698) on the context's stream.
@@ -769,57 +815,45 @@ int enqueue_steps_lagged(msgw_ctx *c, double dt, unsigned flags, int count, bool
 // runs as a standalone k_column, which always lands in the canonical set (c->uu, ...).
 //   per stage:  ONE launch of k_ray_stage (prologue: previous stage's column update from the one
 //   final flux row; tail: in-kernel reduction of its own rows to the next final row)
+template <typename T>
 int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_kernels)
 {
     if (count <= 0) return MSGW_OK;
     const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);
-    StageArgs sa = make_stage_args(c, dt, flags);
-    auto timed = [&](auto &&launch) -> int {
-        c->time_next = time_kernels;
-        const int rc = launch();
-        c->time_next = false;
-        return rc;
-    };
+    StageArgsT<T> sa = make_stage_args<T>(c, dt, flags);
     if (flags & MSGW_FIXED_BACKGROUND) {                       // independent rays: all steps in ONE launch
         sa.fixed_steps = count;
         c->cnt.persist_steps = count;
-        return timed([&] { return launch_fixed(c, sa, mode); });
+        return launch_fixed<T>(c, sa, mode, time_kernels);
     }
     const ColIn in_set[2] = {ColIn{c->uu, c->vv, c->q_uu, c->q_vv}, ColIn{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
     const ColOut out_set[2] = {ColOut{c->uu, c->vv, c->q_uu, c->q_vv}, ColOut{c->alt_uu, c->alt_vv, c->alt_q_uu, c->alt_q_vv}};
     const bool can_fuse = (2 * (c->ng - 2) <= BLOCK) && (c->ng - 1 <= BLOCK);   // one thread per column/level
     if (!can_fuse) {                   // tall columns: standalone column kernel after every stage
         const ColArgs ca = make_col_args(c, dt, flags);
-        for (int step = 0; step < count; ++step) {
-            if (int rc = timed([&] { return launch_stage<0>(c, sa, mode); })) return rc;
-            if (int rc = column_stage<0>(c, ca)) return rc;
-            if (int rc = timed([&] { return launch_stage<1>(c, sa, mode); })) return rc;
-            if (int rc = column_stage<1>(c, ca)) return rc;
-            if (int rc = timed([&] { return launch_stage<2>(c, sa, mode); })) return rc;
-            if (int rc = column_stage<2>(c, ca)) return rc;
-        }
+        for (int step = 0; step < count; ++step)
+            for (int s = 0; s < 3; ++s) {
+                if (int rc = launch_stage<T>(c, s, sa, mode, time_kernels)) return rc;
+                if (int rc = column_stage(c, s, ca)) return rc;
+            }
         return MSGW_OK;
     }
     if (c->nranks > 1 || (c->force_coll && c->comm))   // collectives: overlap them with the next pass
-        return enqueue_steps_lagged(c, dt, flags, count, time_kernels);
+        return enqueue_steps_lagged<T>(c, dt, flags, count, time_kernels);
     int cur = 0;                       // set that holds the column BEFORE the pending update
     bool pending = false;
     int pend_stage = 0;
     sa.col_rows = c->flux;             // every launch reduces its rows to this one row (in-kernel, three
     sa.flux_out = c->flux;             // ticket levels); it is rewritten only after all prologues have read it
+    c->groupred = true;
+    struct Guard { msgw_ctx *c; ~Guard() { c->groupred = false; } } guard{c};
     for (int step = 0; step < count; ++step) {
         for (int s = 0; s < 3; ++s) {
             sa.col_pending = pending ? 1 : 0;
             sa.col_stage = pend_stage;
             sa.cin = in_set[cur];
             sa.cout = out_set[cur ^ 1];
-            int rc = MSGW_OK;
-            c->groupred = true;
-            if (s == 0) rc = timed([&] { return launch_stage<0>(c, sa, mode); });
-            else if (s == 1) rc = timed([&] { return launch_stage<1>(c, sa, mode); });
-            else rc = timed([&] { return launch_stage<2>(c, sa, mode); });
-            c->groupred = false;
-            if (rc) return rc;
+            if (int rc = launch_stage<T>(c, s, sa, mode, time_kernels)) return rc;
             if (pending) cur ^= 1;     // workgroup 0 has published the updated column there
             pending = true;
             pend_stage = s;
@@ -829,7 +863,7 @@ int enqueue_steps(msgw_ctx *c, double dt, unsigned flags, int count, bool time_k
     ColArgs fin = make_col_args(c, dt, flags);
     fin.in = in_set[cur];
     fin.out = out_set[0];
-    return launch_column_t<2, COL_UPDATE>(c, fin);
+    return launch_column(c, 2, COL_UPDATE, fin);
 }
 
 int ready(msgw_ctx *c)
@@ -842,14 +876,15 @@ int ready(msgw_ctx *c)
     return MSGW_OK;
 }
 
-// ---- HPROP_GLOBAL = True: its own per-stage kernel + the standalone column kernel
-size_t hprop_lds_bytes(int ng) { return stage_lds_bytes(ng) + sizeof(double) * (4 * (size_t)(ng - 1) + 2); }
+// ---- HPROP_GLOBAL = True: its own per-stage kernel + the standalone column kernel (float64 only)
+size_t hprop_lds_bytes(const msgw_ctx *c) { return stage_lds_bytes(c) + sizeof(double) * (4 * (size_t)(c->ng - 1) + 2); }
 
 HpropArgs make_hprop_args(msgw_ctx *c, double dt, unsigned flags)
 {
     HpropArgs h{};
-    h.s = make_stage_args(c, dt, flags);
-    h.lam = c->lam; h.phi = c->phi; h.kk = c->kk; h.ll = c->ll;
+    h.s = make_stage_args<double>(c, dt, flags);
+    auto d = [](void *v) { return static_cast<double *>(v); };
+    h.lam = c->lam; h.phi = c->phi; h.kk = d(c->kk); h.ll = d(c->ll);
     h.q_lam = c->q_lam; h.q_phi = c->q_phi; h.q_kk = c->q_kk; h.q_ll = c->q_ll;
     h.uu = c->uu; h.vv = c->vv;
     const double rot = 7.2921e-5;                                  // ROT_EARTH  (lib/libprop.py:4)
@@ -859,36 +894,167 @@ HpropArgs make_hprop_args(msgw_ctx *c, double dt, unsigned flags)
     return h;
 }
 
-template <int STAGE>
-int launch_hprop_stage(msgw_ctx *c, const HpropArgs &h)
+int launch_hprop_stage(msgw_ctx *c, int stage, const HpropArgs &h)
 {
-    const size_t lds = hprop_lds_bytes(c->ng);
-    if (c->sat_online) {
-        auto k = k_ray_stage_hprop<STAGE, true>;
-        if (int rc = ensure_lds(c, k, lds)) return rc;
-        hipLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, h);
-    } else {
-        auto k = k_ray_stage_hprop<STAGE, false>;
-        if (int rc = ensure_lds(c, k, lds)) return rc;
-        hipLaunchKernelGGL(k, dim3(c->blocks), dim3(BLOCK), lds, c->stream, h);
-    }
-    HIPCHK(c, hipGetLastError());
-    return MSGW_OK;
+    return launch_struct(c, hprop_kernel(stage, c->sat_online != 0), c->blocks, BLOCK, hprop_lds_bytes(c), h);
 }
 
 int enqueue_steps_hprop(msgw_ctx *c, double dt, unsigned flags, int count)
 {
     const HpropArgs h = make_hprop_args(c, dt, flags);
     const ColArgs ca = make_col_args(c, dt, flags);
-    for (int step = 0; step < count; ++step) {
-        if (int rc = launch_hprop_stage<0>(c, h)) return rc;
-        if (int rc = column_stage<0>(c, ca)) return rc;
-        if (int rc = launch_hprop_stage<1>(c, h)) return rc;
-        if (int rc = column_stage<1>(c, ca)) return rc;
-        if (int rc = launch_hprop_stage<2>(c, h)) return rc;
-        if (int rc = column_stage<2>(c, ca)) return rc;
-    }
+    for (int step = 0; step < count; ++step)
+        for (int s = 0; s < 3; ++s) {
+            if (int rc = launch_hprop_stage(c, s, h)) return rc;
+            if (int rc = column_stage(c, s, ca)) return rc;
+        }
     return MSGW_OK;
+}
+
+// float32 state <-> the float64 arrays of the C ABI: staged through a float64 device buffer and converted there
+int upload_array(msgw_ctx *c, void *dst, const double *src, int64_t n, double *stage)
+{
+    if (!c->f32) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        return MSGW_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(stage, src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return launch_list(c, convert_kernel_d2f(), (unsigned)((n + 255) / 256), 256, (long long)n, (const double *)stage,
+                       static_cast<float *>(dst));
+}
+int download_array(msgw_ctx *c, double *dst, const void *src, int64_t n, double *stage)
+{
+    if (!c->f32) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        return MSGW_OK;
+    }
+    if (int rc = launch_list(c, convert_kernel_f2d(), (unsigned)((n + 255) / 256), 256, (long long)n,
+                             static_cast<const float *>(src), stage))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(dst, stage, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return MSGW_OK;
+}
+// a float64 staging buffer of `count` arrays of n rays (float32 contexts only; nullptr otherwise)
+struct Staging {
+    double *p = nullptr;
+    ~Staging() { if (p) (void)hipFree(p); }
+};
+
+template <typename T>
+int fill_padding(msgw_ctx *c, int64_t n, int64_t n_pad)
+{
+    auto t = [](void *v) { return static_cast<T *>(v); };
+    struct { void *p; double v; } pad[] = {
+        {c->dens, 0.0}, {c->rr, 0.0}, {c->mm, 1.0}, {c->drr, 1.0}, {c->kk, 1.0}, {c->ll, 0.0},
+        {c->dmm, 0.0}, {c->vol, 0.0}, {c->fray, 0.0}, {c->pvf, 1.0}, {c->q_rr, 0.0}, {c->q_mm, 0.0},
+        {c->q_dens, 0.0}, {c->rr0, 0.0}, {c->mm0, 1.0}, {c->src_dens, 0.0}, {c->src_rr, 0.0}, {c->src_mm, 1.0},
+        {c->cgbuf, 0.0}};
+    for (auto &x : pad)
+        if (int rc = launch_list(c, fill_kernel<T>(), (unsigned)((n_pad - n + 255) / 256), 256, t(x.p), (long long)n,
+                                 (long long)n_pad, (T)x.v))
+            return rc;
+    return MSGW_OK;
+}
+
+template <typename T>
+int step_impl(msgw_ctx *c, double dt, int nsteps, unsigned gflags, bool eager, bool time_kernels)
+{
+    int done = 0;
+    {
+        bool used = false;
+        c->cnt.persist_steps = 0;
+        c->cnt.persist_resident_tiles = 0;
+        if (int rc = run_persistent<T>(c, dt, gflags, nsteps, time_kernels, &used)) return rc;
+        if (used) done = nsteps;
+    }
+    if (done < nsteps && !eager && nsteps >= c->graph_steps) {
+        if (!c->gexec || c->g_dt != dt || c->g_flags != gflags || c->g_n != c->n || c->g_steps != c->graph_steps) {
+            drop_graph(c);
+            bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            int rc = MSGW_OK;
+            if (ok) {
+                rc = enqueue_steps<T>(c, dt, gflags, c->graph_steps, false);
+                hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+                ok = (rc == MSGW_OK) && (e == hipSuccess) && c->graph;
+            }
+            if (ok) ok = hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0) == hipSuccess;
+            if (!ok) {                       // capture unsupported (e.g. a collective): stay eager
+                (void)hipGetLastError();
+                drop_graph(c);
+                c->graph_steps = 0;
+            } else {
+                c->g_dt = dt; c->g_flags = gflags; c->g_n = c->n; c->g_steps = c->graph_steps;
+            }
+        }
+        while (c->gexec && nsteps - done >= c->g_steps) {
+            HIPCHK(c, hipGraphLaunch(c->gexec, c->stream));
+            done += c->g_steps;
+        }
+    }
+    if (done < nsteps)
+        if (int rc = enqueue_steps<T>(c, dt, gflags, nsteps - done, time_kernels)) return rc;
+    return MSGW_OK;
+}
+
+}   // namespace
+
+namespace {
+
+// shared tail of the two projection entry points: launch the projection kernel `fn` on `a`, reduce, copy out
+template <typename PA>
+int run_projection(msgw_ctx *c, PA &a, const void *fn, int tile, int np, const double *G, int nG, double *out)
+{
+    const int ncp = nG - 1;
+    double *dG = nullptr, *dflux = nullptr;
+    HIPCHK(c, hipMalloc(&dG, sizeof(double) * (size_t)nG));
+    if (hipMalloc(&dflux, sizeof(double) * (size_t)np * ncp) != hipSuccess) {
+        (void)hipFree(dG);
+        return fail(c, MSGW_ERR_HIP, "hipMalloc failed in projection");
+    }
+    int rc = MSGW_OK;
+    do {
+        if (hipMemcpyAsync(dG, G, sizeof(double) * (size_t)nG, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "H2D of G failed"); break; }
+        const int64_t ntiles = (a.n + tile - 1) / tile;
+        const int64_t maxb = (int64_t)c->ncu * c->blocks_per_cu;
+        int64_t tpb = (ntiles + maxb - 1) / maxb; if (tpb < 1) tpb = 1;
+        int blocks = (int)((ntiles + tpb - 1) / tpb); if (blocks < 1) blocks = 1;
+        a.tiles_per_block = (int)tpb;
+        if ((rc = ensure_partial(c, blocks, (size_t)np * ncp))) break;
+        a.G = dG; a.partial = c->partial; a.ranges = c->ranges;
+        if ((rc = launch_struct(c, fn, blocks, BLOCK, proj_lds_bytes(nG, np), a))) break;
+        ColArgs ca{};
+        ca.ng = 4; ca.nblocks = blocks; ca.npay = np; ca.ncp = ncp; ca.nseg = pick_nseg(np * ncp);
+        ca.partial = c->partial; ca.ranges = c->ranges; ca.flux = dflux;
+        if ((rc = reduce_level1(c, ca))) break;
+        if ((rc = launch_column(c, 4, COL_REDUCE, ca))) break;
+        std::vector<double> tmp;
+        double *dst = out;
+        if (a.boundary) { tmp.resize((size_t)np * ncp); dst = tmp.data(); }   // var 3/4: rows of nG values, last one 0
+        if (hipMemcpyAsync(dst, dflux, sizeof(double) * (size_t)np * ncp, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "D2H of projection failed"); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "sync failed in projection"); break; }
+        if (a.boundary)
+            for (int p = 0; p < np; ++p) {
+                std::memcpy(out + (size_t)p * nG, tmp.data() + (size_t)p * ncp, sizeof(double) * (size_t)ncp);
+                out[(size_t)p * nG + ncp] = 0.0;
+            }
+    } while (0);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(dG);
+    (void)hipFree(dflux);
+    return rc;
+}
+
+template <typename T>
+int project_resident(msgw_ctx *c, int var, const double *G, int nG, double *out)
+{
+    ProjArgsT<T> a{};
+    // var 3 / 4 (:199-219): the payloads of var 1 / var 0, summed at the interfaces
+    a.n = c->n; a.nG = nG; a.var = (var == 3) ? 1 : (var == 4 ? 0 : var); a.boundary = var >= 3;
+    a.bvf2 = (T)std::pow(c->bvf, 2.0); a.f_uni = (T)c->f_uni; a.dz = (T)(G[1] - G[0]);
+    a.cdz = T(1) / a.dz; a.mk_ok = markstein_ok(a.dz);
+    a.r = ray_ptrs<T>(c);
+    const int np = (var == 0 || var == 4) ? 2 : 1;
+    return run_projection(c, a, project_kernel<T>(np, c->fvec), Real<T>::TILE, np, G, nG, out);
 }
 
 }   // namespace
@@ -900,13 +1066,16 @@ int msgw_abi_version(void) { return MSGW_ABI_VERSION; }
 
 const char *msgw_last_error(const msgw_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
+int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsigned create_flags)
 {
     if (!out) return fail(nullptr, MSGW_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (nray_cap < 1 || ngrid < 4) return fail(nullptr, MSGW_ERR_ARG, "need nray_cap >= 1 and ngrid >= 4");
+    // ngrid >= 5: the scratch of the fused column update (6*ngrid - 6 doubles) aliases the per-wave flux rows
+    // (8*(ngrid - 2) doubles) in LDS
+    if (nray_cap < 1 || ngrid < 5) return fail(nullptr, MSGW_ERR_ARG, "need nray_cap >= 1 and ngrid >= 5");
     if (nray_cap > (1ll << 29))
         return fail(nullptr, MSGW_ERR_ARG, "at most 2^29 rays per context (32-bit byte offsets into the SoA arrays)");
+    if (create_flags & ~MSGW_DTYPE_F32) return fail(nullptr, MSGW_ERR_ARG, "unknown create flag");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, MSGW_ERR_NOGPU, "no HIP device visible (this library has no CPU fallback)");
@@ -919,18 +1088,22 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     msgw_ctx *c = new msgw_ctx();
     c->device = device;
     c->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    snprintf(c->pci_id, sizeof c->pci_id, "%04x:%02x:%02x", prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
     c->cap = nray_cap;
     c->ng = ngrid;
+    c->f32 = (create_flags & MSGW_DTYPE_F32) ? 1 : 0;
+    c->esz = c->f32 ? sizeof(float) : sizeof(double);
+    c->tile = c->f32 ? Real<float>::TILE : Real<double>::TILE;
 #define CR(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int rc_ = fail(nullptr, MSGW_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); msgw_destroy(c); return rc_; } } while (0)
     CR(hipSetDevice(device));
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
-    double **rp[] = {&c->dens, &c->rr, &c->mm, &c->drr, &c->kk, &c->ll, &c->dmm, &c->vol, &c->fray,
-                     &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0, &c->src_dens, &c->src_rr, &c->src_mm, &c->cgbuf};
-    const size_t padded = (((size_t)nray_cap + TILE - 1) / TILE + 1) * TILE;   // whole tiles + one: unconditional vector access
-    for (double **p : rp) {
-        CR(hipMalloc(p, padded * sizeof(double)));
+    void **rp[] = {&c->dens, &c->rr, &c->mm, &c->drr, &c->kk, &c->ll, &c->dmm, &c->vol, &c->fray,
+                   &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0, &c->src_dens, &c->src_rr, &c->src_mm, &c->cgbuf};
+    const size_t padded = (((size_t)nray_cap + c->tile - 1) / c->tile + 1) * c->tile;   // whole tiles + one: unconditional vector access
+    for (void **p : rp) {
+        CR(hipMalloc(p, padded * c->esz));
         c->ray_bufs.push_back(*p);
     }
     // column: one allocation carved into equally sized slots of ng doubles (+ 2 for the flux output)
@@ -940,7 +1113,7 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
     // on c->stream, NOT the null stream: c->stream is non-blocking, so a null-stream fill (asynchronous to the
     // host for device memory) could land after msgw_set_column's uploads and wipe them
     CR(hipMemsetAsync(c->colbuf, 0, slot * nslots * sizeof(double) * 2, c->stream));
-    for (double *p : c->ray_bufs) CR(hipMemsetAsync(p, 0, padded * sizeof(double), c->stream));
+    for (void *p : c->ray_bufs) CR(hipMemsetAsync(p, 0, padded * c->esz, c->stream));
     CR(hipStreamSynchronize(c->stream));
     double *b = c->colbuf;
     c->grid = b; b += slot; c->grids = b; b += slot; c->rhobar = b; b += slot;
@@ -953,11 +1126,17 @@ int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
 #undef CR
     c->cnt.ngrid = ngrid;
     c->cnt.nranks = 1;
+    c->cnt.elem_bytes = (int32_t)c->esz;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_REGTILES")) c->regtiles = std::atoi(e) ? 1 : 0;
     *out = c;
     return MSGW_OK;
+}
+
+int msgw_create(msgw_ctx **out, int device, int64_t nray_cap, int ngrid)
+{
+    return msgw_create_ex(out, device, nray_cap, ngrid, 0u);
 }
 
 int msgw_destroy(msgw_ctx *c)
@@ -969,7 +1148,7 @@ int msgw_destroy(msgw_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     xch_teardown(c);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
-    for (double *p : c->ray_bufs) (void)hipFree(p);
+    for (void *p : c->ray_bufs) (void)hipFree(p);
     if (c->colbuf) (void)hipFree(c->colbuf);
     if (c->partial) (void)hipFree(c->partial);
     if (c->ranges) (void)hipFree(c->ranges);
@@ -979,6 +1158,7 @@ int msgw_destroy(msgw_ctx *c)
     if (c->grp_cnt) (void)hipFree(c->grp_cnt);
     if (c->grp_rows2) (void)hipFree(c->grp_rows2);
     if (c->pdone) (void)hipFree(c->pdone);
+    if (c->pstatus) (void)hipFree(c->pstatus);
     if (c->flux2) (void)hipFree(c->flux2);
     if (c->shtab) (void)hipFree(c->shtab);
     if (c->grp_part2) (void)hipFree(c->grp_part2);
@@ -998,8 +1178,10 @@ int msgw_set_config(msgw_ctx *c, double bvf, double f0, double kappa, int satura
 {
     if (!c) return MSGW_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    if (hprop && c->f32)
+        return fail(c, MSGW_ERR_UNSUP, "HPROP_GLOBAL = True is float64 only (create the context without MSGW_DTYPE_F32)");
     if (hprop && !c->lam) {                                    // the six extra ray arrays of the spherical branch
-        const size_t padded = (((size_t)c->cap + TILE - 1) / TILE + 1) * TILE;
+        const size_t padded = (((size_t)c->cap + c->tile - 1) / c->tile + 1) * c->tile;
         double **hp[] = {&c->lam, &c->phi, &c->q_lam, &c->q_phi, &c->q_kk, &c->q_ll};
         for (double **p : hp) {
             HIPCHK(c, hipMalloc(p, padded * sizeof(double)));
@@ -1037,11 +1219,12 @@ int msgw_set_column(msgw_ctx *c, const double *grid, const double *grids, const 
     c->xg_last = grid[ng - 2];                       // last point of grid[1:-1]
     c->gs_last = grids[nc - 1];
     if (!(c->dzg > 0) || !(c->dzs > 0)) return fail(c, MSGW_ERR_ARG, "grid must be increasing");
-    hipLaunchKernelGGL(k_rho_slopes, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, c->grids, c->rhobar, c->slrho);
-    HIPCHK(c, hipGetLastError());
+    if (int rc = launch_list(c, rho_slopes_kernel(), (unsigned)((nc + 255) / 256), 256, (int)nc, (const double *)c->grids,
+                             (const double *)c->rhobar, c->slrho))
+        return rc;
     ColArgs a = make_col_args(c, 0.0, 0);
     a.nblocks = 0; a.nseg = 1;
-    if (int rc = launch_column_t<4, COL_UPDATE>(c, a)) return rc;
+    if (int rc = launch_column(c, 4, COL_UPDATE, a)) return rc;
     c->have_column = true;
     return MSGW_OK;
 }
@@ -1055,31 +1238,55 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
     if (!dens || !rr || !drr || !kk || !ll || !mm || !dmm || !fray || !dkk || !dll || !area)
         return fail(c, MSGW_ERR_ARG, "NULL ray pointer");
     HIPCHK(c, hipSetDevice(c->device));
+    // float64 staging of what k_prepare reads in float64 (dkk, dll, area, drr, dmm) -- and, for a float32 state, of
+    // every array on its way to the conversion kernel
+    Staging st;
+    const size_t nstage = c->f32 ? 6 : 3;
+    HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)n * nstage));
+    double *s_dkk = st.p, *s_dll = st.p + n, *s_area = st.p + 2 * n;
     const size_t B = (size_t)n * sizeof(double);
-    struct { double *d; const double *h; } cp[] = {
-        {c->dens, dens}, {c->rr, rr}, {c->drr, drr}, {c->kk, kk}, {c->ll, ll}, {c->mm, mm},
-        {c->dmm, dmm}, {c->fray, fray}, {c->q_rr, dkk}, {c->q_mm, dll}, {c->q_dens, area}};
-    for (auto &x : cp) HIPCHK(c, hipMemcpyAsync(x.d, x.h, B, hipMemcpyHostToDevice, c->stream));
-    // the source a recycled slot returns to (MSGW_RELAUNCH) is the state at upload
-    HIPCHK(c, hipMemcpyAsync(c->src_dens, c->dens, B, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->src_rr, c->rr, B, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->src_mm, c->mm, B, hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(k_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (long long)n,
-                       c->q_rr, c->q_mm, c->q_dens, c->drr, c->dmm, c->vol, c->pvf);
-    HIPCHK(c, hipGetLastError());
-    // inert padding up to a whole tile (finite, never deposited: validity is index < n)
-    const long long n_pad = ((n + TILE - 1) / TILE + 1) * TILE;   // a workgroup's last tile may overhang by < TILE
-    if (n_pad > n) {
-        struct { double *p; double v; } pad[] = {
-            {c->dens, 0.0}, {c->rr, 0.0}, {c->mm, 1.0}, {c->drr, 1.0}, {c->kk, 1.0}, {c->ll, 0.0},
-            {c->dmm, 0.0}, {c->vol, 0.0}, {c->fray, 0.0}, {c->pvf, 1.0}, {c->q_rr, 0.0}, {c->q_mm, 0.0},
-            {c->q_dens, 0.0}, {c->rr0, 0.0}, {c->mm0, 1.0}, {c->src_dens, 0.0}, {c->src_rr, 0.0}, {c->src_mm, 1.0}};
-        for (auto &x : pad)
-            hipLaunchKernelGGL(k_fill_range, dim3((unsigned)((n_pad - n + 255) / 256)), dim3(256), 0, c->stream,
-                               x.p, (long long)n, n_pad, x.v);
-        HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(s_dkk, dkk, B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s_dll, dll, B, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s_area, area, B, hipMemcpyHostToDevice, c->stream));
+    const double *d_drr, *d_dmm;
+    if (!c->f32) {
+        struct { void *d; const double *h; } cp[] = {
+            {c->dens, dens}, {c->rr, rr}, {c->drr, drr}, {c->kk, kk}, {c->ll, ll}, {c->mm, mm}, {c->dmm, dmm}, {c->fray, fray}};
+        for (auto &x : cp) HIPCHK(c, hipMemcpyAsync(x.d, x.h, B, hipMemcpyHostToDevice, c->stream));
+        d_drr = static_cast<const double *>(c->drr);
+        d_dmm = static_cast<const double *>(c->dmm);
+    } else {
+        double *s_drr = st.p + 3 * n, *s_dmm = st.p + 4 * n, *s_tmp = st.p + 5 * n;
+        if (int rc = upload_array(c, c->drr, drr, n, s_drr)) return rc;
+        if (int rc = upload_array(c, c->dmm, dmm, n, s_dmm)) return rc;
+        struct { void *d; const double *h; } cp[] = {
+            {c->dens, dens}, {c->rr, rr}, {c->kk, kk}, {c->ll, ll}, {c->mm, mm}, {c->fray, fray}};
+        for (auto &x : cp)
+            if (int rc = upload_array(c, x.d, x.h, n, s_tmp)) return rc;     // stream-ordered reuse of s_tmp
+        d_drr = s_drr;
+        d_dmm = s_dmm;
     }
+    // the source a recycled slot returns to (MSGW_RELAUNCH) is the state at upload
+    const size_t BE = (size_t)n * c->esz;
+    HIPCHK(c, hipMemcpyAsync(c->src_dens, c->dens, BE, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->src_rr, c->rr, BE, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->src_mm, c->mm, BE, hipMemcpyDeviceToDevice, c->stream));
+    const unsigned pg = (unsigned)((n + 255) / 256);
+    int rc;
+    if (c->f32)
+        rc = launch_list(c, prepare_kernel<float>(), pg, 256, (long long)n, (const double *)s_dkk, (const double *)s_dll,
+                         (const double *)s_area, d_drr, d_dmm, static_cast<float *>(c->vol), static_cast<float *>(c->pvf));
+    else
+        rc = launch_list(c, prepare_kernel<double>(), pg, 256, (long long)n, (const double *)s_dkk, (const double *)s_dll,
+                         (const double *)s_area, d_drr, d_dmm, static_cast<double *>(c->vol), static_cast<double *>(c->pvf));
+    if (rc) return rc;
+    // inert padding up to a whole tile (finite, never deposited: validity is index < n)
+    const long long n_pad = ((n + c->tile - 1) / c->tile + 1) * c->tile;   // a workgroup's last tile may overhang by < TILE
+    if (n_pad > n)
+        if (int rc2 = c->f32 ? fill_padding<float>(c, n, n_pad) : fill_padding<double>(c, n, n_pad)) return rc2;
+    if (c->pstatus) HIPCHK(c, hipMemsetAsync(c->pstatus, 0, 128, c->stream));   // a fresh state: forget an old time-out
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->status_armed = false;
     // a single latitude for all rays (the 1-D column case, raytracer.py:87) keeps f in a scalar
     bool uni = true;
     for (int64_t i = 1; i < n && uni; ++i) uni = (std::memcmp(&fray[i], &fray[0], sizeof(double)) == 0);
@@ -1087,8 +1294,8 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
     c->f_uni = fray[0];
     c->n = n;
     geometry(c, n);
-    if (int rc = ensure_partial(c, c->blocks, (size_t)2 * (c->ng - 2))) return rc;
-    if (int rc = ensure_groups(c)) return rc;
+    if (int rc3 = ensure_partial(c, c->blocks, (size_t)2 * (c->ng - 2))) return rc3;
+    if (int rc3 = ensure_groups(c)) return rc3;
     c->have_rays = true;
     c->have_hprop = false;                                     // lam, phi belong to the previous set of rays
     c->cnt.nray = n;
@@ -1117,8 +1324,8 @@ int msgw_download_hprop(msgw_ctx *c, int64_t n, int tendencies, double *lam, dou
     if (!c->hprop || !c->have_hprop || n != c->n) return fail(c, MSGW_ERR_ARG, "no HPROP state of that size on the device");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t B = (size_t)n * sizeof(double);
-    const double *src[4] = {tendencies ? c->q_lam : c->lam, tendencies ? c->q_phi : c->phi,
-                            tendencies ? c->q_kk : c->kk, tendencies ? c->q_ll : c->ll};
+    const void *src[4] = {tendencies ? c->q_lam : c->lam, tendencies ? c->q_phi : c->phi,
+                          tendencies ? (const void *)c->q_kk : c->kk, tendencies ? (const void *)c->q_ll : c->ll};
     double *dst[4] = {lam, phi, kk, ll};
     for (int i = 0; i < 4; ++i)
         if (dst[i]) HIPCHK(c, hipMemcpyAsync(dst[i], src[i], B, hipMemcpyDeviceToHost, c->stream));
@@ -1177,39 +1384,9 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
         c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
         return MSGW_OK;
     }
-    int done = 0;
-    {
-        bool used = false;
-        c->cnt.persist_steps = 0;
-        if (int rc = run_persistent(c, dt, gflags, nsteps, time_kernels, &used)) return rc;
-        if (used) done = nsteps;
-    }
-    if (done < nsteps && !eager && nsteps >= c->graph_steps) {
-        if (!c->gexec || c->g_dt != dt || c->g_flags != gflags || c->g_n != c->n || c->g_steps != c->graph_steps) {
-            drop_graph(c);
-            bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            int rc = MSGW_OK;
-            if (ok) {
-                rc = enqueue_steps(c, dt, gflags, c->graph_steps, false);
-                hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
-                ok = (rc == MSGW_OK) && (e == hipSuccess) && c->graph;
-            }
-            if (ok) ok = hipGraphInstantiate(&c->gexec, c->graph, nullptr, nullptr, 0) == hipSuccess;
-            if (!ok) {                       // capture unsupported (e.g. a collective): stay eager
-                (void)hipGetLastError();
-                drop_graph(c);
-                c->graph_steps = 0;
-            } else {
-                c->g_dt = dt; c->g_flags = gflags; c->g_n = c->n; c->g_steps = c->graph_steps;
-            }
-        }
-        while (c->gexec && nsteps - done >= c->g_steps) {
-            HIPCHK(c, hipGraphLaunch(c->gexec, c->stream));
-            done += c->g_steps;
-        }
-    }
-    if (done < nsteps)
-        if (int rc = enqueue_steps(c, dt, gflags, nsteps - done, time_kernels)) return rc;
+    if (int rc = c->f32 ? step_impl<float>(c, dt, nsteps, gflags, eager, time_kernels)
+                        : step_impl<double>(c, dt, nsteps, gflags, eager, time_kernels))
+        return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
     c->cnt.graph_steps = c->gexec ? c->g_steps : 0;
@@ -1221,6 +1398,7 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
             c->cnt.ray_kernel_ms_sum += ms;
             c->cnt.ray_kernel_launches += 1;
         }
+        return check_status(c);
     }
     return MSGW_OK;
 }
@@ -1230,75 +1408,28 @@ int msgw_rhs(msgw_ctx *c, double dt, unsigned flags, double *st_dens, double *st
 {
     if (int rc = ready(c)) return rc;
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_status(c)) return rc;
     if (c->hprop) {
         const HpropArgs h = make_hprop_args(c, dt, flags);
-        if (int rc = launch_hprop_stage<3>(c, h)) return rc;
+        if (int rc = launch_hprop_stage(c, 3, h)) return rc;
+    } else if (c->f32) {
+        if (int rc = launch_probe<float>(c, make_stage_args<float>(c, dt, flags), c->sat_online != 0, true)) return rc;
     } else {
-        const StageArgs sa = make_stage_args(c, dt, flags);
-        if (int rc = launch_probe(c, sa, c->sat_online != 0, true)) return rc;
+        if (int rc = launch_probe<double>(c, make_stage_args<double>(c, dt, flags), c->sat_online != 0, true)) return rc;
     }
     const ColArgs ca = make_col_args(c, dt, flags);
-    if (int rc = column_stage<3>(c, ca)) return rc;
-    const size_t B = (size_t)c->n * sizeof(double), nc = c->ng - 1;
-    if (st_dens) HIPCHK(c, hipMemcpyAsync(st_dens, c->q_dens, B, hipMemcpyDeviceToHost, c->stream));
-    if (st_rr) HIPCHK(c, hipMemcpyAsync(st_rr, c->q_rr, B, hipMemcpyDeviceToHost, c->stream));
-    if (st_mm) HIPCHK(c, hipMemcpyAsync(st_mm, c->q_mm, B, hipMemcpyDeviceToHost, c->stream));
+    if (int rc = column_stage(c, 3, ca)) return rc;
+    const size_t nc = c->ng - 1;
+    Staging st;
+    if (c->f32) HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)c->n * 3));
+    if (st_dens) if (int rc = download_array(c, st_dens, c->q_dens, c->n, st.p)) return rc;
+    if (st_rr) if (int rc = download_array(c, st_rr, c->q_rr, c->n, st.p ? st.p + c->n : nullptr)) return rc;
+    if (st_mm) if (int rc = download_array(c, st_mm, c->q_mm, c->n, st.p ? st.p + 2 * c->n : nullptr)) return rc;
     if (st_uu) HIPCHK(c, hipMemcpyAsync(st_uu, c->out_du, nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (st_vv) HIPCHK(c, hipMemcpyAsync(st_vv, c->out_dv, nc * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (pm_flux) HIPCHK(c, hipMemcpyAsync(pm_flux, c->out_flux, 2 * (size_t)c->ng * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSGW_OK;
-}
-
-// shared tail of the two projection entry points: launch k_project on `a`, reduce, copy out
-static int run_projection(msgw_ctx *c, ProjArgs &a, bool expl, int np, const double *G, int nG, double *out)
-{
-    const int ncp = nG - 1;
-    double *dG = nullptr, *dflux = nullptr;
-    HIPCHK(c, hipMalloc(&dG, sizeof(double) * (size_t)nG));
-    if (hipMalloc(&dflux, sizeof(double) * (size_t)np * ncp) != hipSuccess) {
-        (void)hipFree(dG);
-        return fail(c, MSGW_ERR_HIP, "hipMalloc failed in projection");
-    }
-    int rc = MSGW_OK;
-    do {
-        if (hipMemcpyAsync(dG, G, sizeof(double) * (size_t)nG, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "H2D of G failed"); break; }
-        const int64_t ntiles = (a.n + TILE - 1) / TILE;
-        const int64_t maxb = (int64_t)c->ncu * c->blocks_per_cu;
-        int64_t tpb = (ntiles + maxb - 1) / maxb; if (tpb < 1) tpb = 1;
-        int blocks = (int)((ntiles + tpb - 1) / tpb); if (blocks < 1) blocks = 1;
-        a.tiles_per_block = (int)tpb;
-        if ((rc = ensure_partial(c, blocks, (size_t)np * ncp))) break;
-        a.G = dG; a.partial = c->partial; a.ranges = c->ranges;
-        const size_t lds = proj_lds_bytes(nG, np);
-#define LP_(NP, FV, EX) do { auto k = k_project<NP, FV, EX>; if ((rc = ensure_lds(c, k, lds))) break; \
-            hipLaunchKernelGGL(k, dim3(blocks), dim3(BLOCK), lds, c->stream, a); } while (0)
-        if (expl) { if (np == 2) LP_(2, true, true); else LP_(1, true, true); }
-        else if (np == 2) { if (c->fvec) LP_(2, true, false); else LP_(2, false, false); }
-        else { if (c->fvec) LP_(1, true, false); else LP_(1, false, false); }
-#undef LP_
-        if (rc) break;
-        if (hipGetLastError() != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "k_project launch failed"); break; }
-        ColArgs ca{};
-        ca.ng = 4; ca.nblocks = blocks; ca.npay = np; ca.ncp = ncp; ca.nseg = pick_nseg(np * ncp);
-        ca.partial = c->partial; ca.ranges = c->ranges; ca.flux = dflux;
-        if ((rc = reduce_level1(c, ca))) break;
-        if ((rc = launch_column_t<4, COL_REDUCE>(c, ca))) break;
-        std::vector<double> tmp;
-        double *dst = out;
-        if (a.boundary) { tmp.resize((size_t)np * ncp); dst = tmp.data(); }   // var 3/4: rows of nG values, last one 0
-        if (hipMemcpyAsync(dst, dflux, sizeof(double) * (size_t)np * ncp, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "D2H of projection failed"); break; }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, MSGW_ERR_HIP, "sync failed in projection"); break; }
-        if (a.boundary)
-            for (int p = 0; p < np; ++p) {
-                std::memcpy(out + (size_t)p * nG, tmp.data() + (size_t)p * ncp, sizeof(double) * (size_t)ncp);
-                out[(size_t)p * nG + ncp] = 0.0;
-            }
-    } while (0);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(dG);
-    (void)hipFree(dflux);
-    return rc;
 }
 
 int msgw_project(msgw_ctx *c, int var, const double *G, int nG, double *out)
@@ -1307,14 +1438,8 @@ int msgw_project(msgw_ctx *c, int var, const double *G, int nG, double *out)
     if (var < 0 || var > 4) return fail(c, MSGW_ERR_ARG, "wave_projection var=%d: must be 0 .. 4", var);
     if (!G || !out || nG < 3) return fail(c, MSGW_ERR_ARG, "bad projection grid");
     HIPCHK(c, hipSetDevice(c->device));
-    ProjArgs a{};
-    // var 3 / 4 (:199-219): the payloads of var 1 / var 0, summed at the interfaces
-    a.n = c->n; a.nG = nG; a.var = (var == 3) ? 1 : (var == 4 ? 0 : var); a.boundary = var >= 3;
-    a.bvf2 = std::pow(c->bvf, 2.0); a.f_uni = c->f_uni; a.dz = G[1] - G[0];
-    a.cdz = 1.0 / a.dz; a.mk_ok = markstein_ok(a.dz);
-    a.r = RayPtrs{c->dens, c->rr, c->mm, c->drr, c->kk, c->ll, c->dmm, c->vol, c->fray, c->pvf,
-                  c->q_rr, c->q_mm, c->q_dens, c->rr0, c->mm0, c->src_dens, c->src_rr, c->src_mm, c->cgbuf};
-    return run_projection(c, a, false, (var == 0 || var == 4) ? 2 : 1, G, nG, out);
+    if (int rc = check_status(c)) return rc;
+    return c->f32 ? project_resident<float>(c, var, G, nG, out) : project_resident<double>(c, var, G, nG, out);
 }
 
 int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const double *dens,
@@ -1328,7 +1453,8 @@ int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const doubl
     const double *h[11] = {dens, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, fray};
     for (const double *p : h) if (!p) return fail(c, MSGW_ERR_ARG, "NULL array");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t padded = (((size_t)n + TILE - 1) / TILE) * TILE;
+    const int tile = Real<double>::TILE;                       // caller arrays are float64 whatever the context holds
+    const size_t padded = (((size_t)n + tile - 1) / tile) * tile;
     double *buf = nullptr;
     HIPCHK(c, hipMalloc(&buf, sizeof(double) * padded * 11));
     int rc = MSGW_OK;
@@ -1346,7 +1472,8 @@ int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const doubl
         a.bvf2 = std::pow(bvf, 2.0); a.f_uni = 0.0; a.dz = G[1] - G[0];
         a.cdz = 1.0 / a.dz; a.mk_ok = markstein_ok(a.dz);
         a.e = ProjExplicit{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]};
-        rc = run_projection(c, a, true, (var == 0 || var == 4) ? 2 : 1, G, nG, out);
+        const int np = (var == 0 || var == 4) ? 2 : 1;
+        rc = run_projection(c, a, project_arrays_kernel(np), tile, np, G, nG, out);
     }
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(buf);
@@ -1382,9 +1509,8 @@ int msgw_saturation(msgw_ctx *c, int64_t n, double dt, int direct, const double 
         a.dkk = b + 9 * n; a.dll = b + 10 * n; a.area = b + 11 * n;
         a.grids = c->grids; a.rhobar = c->rhobar; a.slrho = c->slrho;
         a.out = buf + (size_t)n * 12;
-        hipLaunchKernelGGL(k_saturation, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, a);
-        if (hipGetLastError() != hipSuccess) rc = fail(c, MSGW_ERR_HIP, "k_saturation launch failed");
-        else if (hipMemcpyAsync(out, a.out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = launch_struct(c, saturation_kernel(), (unsigned)((n + BLOCK - 1) / BLOCK), BLOCK, 0, a);
+        if (rc == MSGW_OK && hipMemcpyAsync(out, a.out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
             rc = fail(c, MSGW_ERR_HIP, "D2H failed in msgw_saturation");
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == MSGW_OK) rc = fail(c, MSGW_ERR_HIP, "sync failed in msgw_saturation");
@@ -1397,10 +1523,12 @@ int msgw_download_rays(msgw_ctx *c, int64_t n, double *dens, double *rr, double 
     if (!c || !c->have_rays) return fail(c, MSGW_ERR_ARG, "no rays resident");
     if (n != c->n) return fail(c, MSGW_ERR_ARG, "n=%lld but %lld rays are resident", (long long)n, (long long)c->n);
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t B = (size_t)n * sizeof(double);
-    if (dens) HIPCHK(c, hipMemcpyAsync(dens, c->dens, B, hipMemcpyDeviceToHost, c->stream));
-    if (rr) HIPCHK(c, hipMemcpyAsync(rr, c->rr, B, hipMemcpyDeviceToHost, c->stream));
-    if (mm) HIPCHK(c, hipMemcpyAsync(mm, c->mm, B, hipMemcpyDeviceToHost, c->stream));
+    if (int rc = check_status(c)) return rc;
+    Staging st;
+    if (c->f32) HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)n * 3));
+    if (dens) if (int rc = download_array(c, dens, c->dens, n, st.p)) return rc;
+    if (rr) if (int rc = download_array(c, rr, c->rr, n, st.p ? st.p + n : nullptr)) return rc;
+    if (mm) if (int rc = download_array(c, mm, c->mm, n, st.p ? st.p + 2 * n : nullptr)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSGW_OK;
 }
@@ -1409,6 +1537,7 @@ int msgw_download_column(msgw_ctx *c, double *uu, double *vv)
 {
     if (!c || !c->have_column) return fail(c, MSGW_ERR_ARG, "no column resident");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_status(c)) return rc;
     const size_t B = (size_t)(c->ng - 1) * sizeof(double);
     if (uu) HIPCHK(c, hipMemcpyAsync(uu, c->uu, B, hipMemcpyDeviceToHost, c->stream));
     if (vv) HIPCHK(c, hipMemcpyAsync(vv, c->vv, B, hipMemcpyDeviceToHost, c->stream));
@@ -1421,7 +1550,7 @@ int msgw_sync(msgw_ctx *c)
     if (!c) return MSGW_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return MSGW_OK;
+    return check_status(c);
 }
 
 int msgw_comm_unique_id(void *id128)
@@ -1446,10 +1575,14 @@ double now_s()
 
 void xch_teardown(msgw_ctx *c)
 {
+    for (void *p : c->xch_peer_open) (void)hipIpcCloseMemHandle(p);
+    c->xch_peer_open.clear();
+    if (c->xch_local) { (void)hipFree(c->xch_local); c->xch_local = nullptr; }
     if (c->xch_registered) { (void)hipHostUnregister(c->xch_hdr); c->xch_registered = false; }
     if (c->xch_hdr) { munmap(c->xch_hdr, c->xch_bytes); c->xch_hdr = nullptr; }
     if (c->xch_scratch) { (void)hipFree(c->xch_scratch); c->xch_scratch = nullptr; }
-    c->xch_rows = nullptr; c->xch_flags = nullptr; c->xch_ok = false; c->xch_bytes = 0;
+    c->xch_rows = nullptr; c->xch_flags = nullptr; c->xch_peer_rows = nullptr; c->xch_peer_flags = nullptr;
+    c->xch_ok = false; c->xch_bytes = 0; c->xch_direct = false; c->tenants = 1;
 }
 
 // Host barrier `k` of the set-up: every rank reports `ok`; returns true when all ranks arrived in
@@ -1467,6 +1600,33 @@ bool xch_barrier(msgw_ctx *c, int k, bool ok, double timeout_s)
     return __atomic_load_n(&h->okay[k], __ATOMIC_ACQUIRE) == (unsigned int)c->nranks;
 }
 
+// Per-call agreement of the ranks of one node (host side, through the segment header): every rank publishes
+// `mine`; *all = every rank said yes.  Values are double-buffered by the parity of the call counter: a rank can
+// only start call k+2 after every rank has finished reading call k.  False = a rank did not show up in time.
+bool xch_agree_step(msgw_ctx *c, bool mine, bool *all)
+{
+    XchHeader *h = c->xch_hdr;
+    *all = mine;
+    if (!h || c->nranks <= 1) return true;
+    const unsigned long long k = ++c->xch_calls;
+    __atomic_store_n(&h->agree_val[c->rank][k & 1], mine ? 1u : 0u, __ATOMIC_RELAXED);
+    __atomic_store_n(&h->agree_cnt[c->rank], k, __ATOMIC_RELEASE);
+    const double t0 = now_s();
+    bool yes = true;
+    for (int r = 0; r < c->nranks; ++r) {
+        unsigned spins = 0;
+        while (__atomic_load_n(&h->agree_cnt[r], __ATOMIC_ACQUIRE) < k) {
+            if ((++spins & 1023u) == 0) {
+                if (now_s() - t0 > 60.0) return false;
+                usleep(50);
+            }
+        }
+        yes = yes && __atomic_load_n(&h->agree_val[r][k & 1], __ATOMIC_RELAXED) != 0u;
+    }
+    *all = yes;
+    return true;
+}
+
 // When there is an RCCL communicator the outcome is also agreed through it (covers ranks on
 // other nodes, which can never join this node's segment).
 bool xch_agree_rccl(msgw_ctx *c, bool ok)
@@ -1480,14 +1640,34 @@ bool xch_agree_rccl(msgw_ctx *c, bool ok)
     return v == 1;
 }
 
-// Create/join the communicator's segment, map it into the GPU, run the self-test, agree.  Never
+// `rounds` node-level sums of known rows through the very code path of the persistent kernel, with the transport
+// described by `x` (sequence numbers x.seq + 1 ...).
+bool xch_selftest(msgw_ctx *c, const XchArgs &x)
+{
+    XchTestArgs t{};
+    t.x = x; t.rounds = XCH_TEST_ROUNDS; t.result = c->xch_scratch;
+    int res = 0;
+    if (hipMemsetAsync(c->xch_scratch, 0, 64, c->stream) != hipSuccess) return false;
+    if (launch_struct(c, xch_selftest_kernel(), 1, BLOCK, 0, t) != MSGW_OK) return false;
+    return hipMemcpyAsync(&res, c->xch_scratch, sizeof res, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+           hipStreamSynchronize(c->stream) == hipSuccess && res == 1;
+}
+
+// Create/join the communicator's segment, set up the transports, run the self-tests, agree.  Never
 // fatal: on any failure xch_ok stays false and multi-rank steps use the all-reduce launch chain.
-void xch_setup(msgw_ctx *c, const void *id128, std::string &why)
+//  1. POSIX shared-memory segment (bootstrap + host barriers + per-call agreement; also the fallback transport,
+//     registered with the GPU as fine-grained host memory);
+//  2. device-resident transport: every rank allocates its exchange buffer in its own HBM, publishes the HIP IPC
+//     handle in the segment and maps the buffers of all other ranks (xGMI peer writes; two ranks that share one GPU
+//     in a rehearsal map each other's buffers in the same HBM);
+//  3. the ranks count how many of them share each physical device (`tenants`): they split its residency slots.
+void xch_setup(msgw_ctx *c, const void *id128, std::string &why, int want_direct)
 {
     xch_teardown(c);
     c->xch_seq = 0;
-    if (c->nranks > 64) { why = "more than 64 ranks (one polling lane per rank)"; return; }   // the same on every rank
-    if (hipMalloc(&c->xch_scratch, 256) != hipSuccess) { (void)hipGetLastError(); why = "hipMalloc"; return; }
+    c->xch_calls = 0;
+    if (c->nranks > XCH_MAX_RANKS) { why = "more than 64 ranks (one polling lane per rank)"; return; }   // the same on every rank
+    if (hipMalloc(&c->xch_scratch, XCH_SCRATCH_BYTES) != hipSuccess) { (void)hipGetLastError(); why = "hipMalloc"; return; }
     // the name is derived from the communicator's unique id (FNV-1a), identical on all ranks
     unsigned long long hsh = 1469598103934665603ull;
     for (int i = 0; i < 128; ++i) hsh = (hsh ^ ((const unsigned char *)id128)[i]) * 1099511628211ull;
@@ -1497,7 +1677,8 @@ void xch_setup(msgw_ctx *c, const void *id128, std::string &why)
     const int stride = ((ncols > 64 ? ncols : 64) + 7) / 8 * 8;
     const size_t flags_bytes = ((size_t)c->nranks * 64 + 4095) / 4096 * 4096;
     const size_t rows_off = XCH_FLAGS_OFF + flags_bytes;
-    const size_t bytes = (rows_off + sizeof(double) * 2 * (size_t)c->nranks * stride + 4095) / 4096 * 4096;
+    const size_t rows_bytes = sizeof(double) * 2 * (size_t)c->nranks * stride;
+    const size_t bytes = (rows_off + rows_bytes + 4095) / 4096 * 4096;
     const double join_timeout = 60.0;
     int fd = -1;
     bool ok = true;
@@ -1543,30 +1724,98 @@ void xch_setup(msgw_ctx *c, const void *id128, std::string &why)
         else { (void)hipGetLastError(); ok = false; why = "hipHostRegister"; }
     }
     if (ok && hipHostGetDevicePointer(&dev, m, 0) != hipSuccess) { (void)hipGetLastError(); ok = false; why = "hipHostGetDevicePointer"; }
+    // device-resident transport, part 1: my buffer and its IPC handle
+    XchPeerSlot *slots = reinterpret_cast<XchPeerSlot *>(static_cast<char *>(m) + XCH_PEERS_OFF);
+    const size_t local_bytes = flags_bytes + rows_bytes;
+    bool direct = ok && want_direct != 0;
+    if (ok) {
+        std::memset(&slots[c->rank], 0, sizeof(XchPeerSlot));
+        std::memcpy(slots[c->rank].pci, c->pci_id, sizeof c->pci_id);
+        if (direct) {
+            // fine-grained device memory: peers' writes must become visible to a running kernel
+            if (hipExtMallocWithFlags(&c->xch_local, local_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+                (void)hipGetLastError();
+                c->xch_local = nullptr;
+                direct = false;
+            }
+            if (direct && hipMemset(c->xch_local, 0, local_bytes) != hipSuccess) direct = false;
+            hipIpcMemHandle_t hd;
+            if (direct && hipIpcGetMemHandle(&hd, c->xch_local) == hipSuccess) {
+                static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(slots[0].handle), "IPC handle does not fit its slot");
+                std::memcpy(slots[c->rank].handle, &hd, sizeof hd);
+                slots[c->rank].has_handle = 1;
+            } else if (direct) {
+                (void)hipGetLastError();
+                direct = false;
+            }
+        }
+    }
     ok = xch_barrier(c, 0, ok, join_timeout) && ok;            // everybody has opened the segment ...
     if (c->rank == 0) shm_unlink(name);                        // ... so its name can go
     if (ok) {
-        c->xch_flags = reinterpret_cast<unsigned long long *>(static_cast<char *>(dev) + XCH_FLAGS_OFF);
-        c->xch_rows = reinterpret_cast<double *>(static_cast<char *>(dev) + rows_off);
+        // ranks that share this rank's physical device split its residency slots
+        int tenants = 0;
+        for (int r = 0; r < c->nranks; ++r)
+            if (std::memcmp(slots[r].pci, c->pci_id, sizeof c->pci_id) == 0) ++tenants;
+        c->tenants = tenants > 0 ? tenants : 1;
         c->xch_stride = stride;
-        XchTestArgs t{};
-        t.nranks = c->nranks; t.rank = c->rank; t.stride = stride; t.rounds = XCH_TEST_ROUNDS;
-        t.rows = c->xch_rows; t.flags = c->xch_flags; t.timeout_ticks = XCH_TIMEOUT_TICKS; t.result = c->xch_scratch;
-        int res = 0;
-        ok = hipMemsetAsync(c->xch_scratch, 0, 64, c->stream) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL(k_xch_selftest, dim3(1), dim3(BLOCK), 0, c->stream, t);
-            ok = hipGetLastError() == hipSuccess &&
-                 hipMemcpyAsync(&res, c->xch_scratch, sizeof res, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-                 hipStreamSynchronize(c->stream) == hipSuccess && res == 1;
+        XchArgs x{};
+        x.nranks = c->nranks; x.rank = c->rank; x.stride = stride; x.timeout_ticks = XCH_TIMEOUT_TICKS;
+        // device-resident transport, part 2: map every other rank's buffer, self-test, agree
+        for (int r = 0; r < c->nranks && direct; ++r) direct = slots[r].has_handle != 0;
+        std::vector<double *> prow(c->nranks, nullptr);
+        std::vector<unsigned long long *> pflag(c->nranks, nullptr);
+        for (int r = 0; r < c->nranks && direct; ++r) {
+            void *p = c->xch_local;
+            if (r != c->rank) {
+                hipIpcMemHandle_t hd;
+                std::memcpy(&hd, slots[r].handle, sizeof hd);
+                if (hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); direct = false; break; }
+                c->xch_peer_open.push_back(p);
+            }
+            pflag[r] = reinterpret_cast<unsigned long long *>(p);
+            prow[r] = reinterpret_cast<double *>(static_cast<char *>(p) + flags_bytes);
         }
-        if (!ok) why = "self-test (rows of the other ranks not seen)";
+        double **d_prow = reinterpret_cast<double **>(reinterpret_cast<char *>(c->xch_scratch) + XCH_SCRATCH_PEERS);
+        unsigned long long **d_pflag = reinterpret_cast<unsigned long long **>(d_prow + XCH_MAX_RANKS);
+        if (direct)
+            direct = hipMemcpy(d_prow, prow.data(), sizeof(double *) * c->nranks, hipMemcpyHostToDevice) == hipSuccess &&
+                     hipMemcpy(d_pflag, pflag.data(), sizeof(void *) * c->nranks, hipMemcpyHostToDevice) == hipSuccess;
+        bool d_ok = direct;
+        if (xch_barrier(c, 1, direct, join_timeout)) {         // every rank has mapped every buffer
+            x.direct = 1; x.rows = prow[c->rank]; x.flags = pflag[c->rank];
+            x.peer_rows = d_prow; x.peer_flags = d_pflag; x.seq = 0;
+            d_ok = xch_selftest(c, x);
+        } else {
+            d_ok = false;
+        }
+        d_ok = xch_barrier(c, 2, d_ok, join_timeout) && d_ok;
+        d_ok = xch_agree_rccl(c, d_ok);
+        if (d_ok) {
+            c->xch_direct = true;
+            c->xch_rows = x.rows; c->xch_flags = x.flags; c->xch_peer_rows = d_prow; c->xch_peer_flags = d_pflag;
+            c->xch_seq = XCH_TEST_ROUNDS;                      // the self-test used sequence numbers 1..rounds
+        } else {
+            // fallback transport: rows and sequence numbers in the host segment
+            x = XchArgs{};
+            x.nranks = c->nranks; x.rank = c->rank; x.stride = stride; x.timeout_ticks = XCH_TIMEOUT_TICKS;
+            x.rows = reinterpret_cast<double *>(static_cast<char *>(dev) + rows_off);
+            x.flags = reinterpret_cast<unsigned long long *>(static_cast<char *>(dev) + XCH_FLAGS_OFF);
+            x.seq = 0;
+            ok = xch_selftest(c, x);
+            if (!ok) why = "self-test (rows of the other ranks not seen)";
+            ok = xch_barrier(c, 3, ok, join_timeout) && ok;
+            ok = xch_agree_rccl(c, ok);
+            if (ok) {
+                c->xch_rows = x.rows; c->xch_flags = x.flags;
+                c->xch_seq = XCH_TEST_ROUNDS;
+            }
+        }
+    } else {
+        (void)xch_agree_rccl(c, false);
     }
-    ok = xch_barrier(c, 1, ok, join_timeout) && ok;
-    ok = xch_agree_rccl(c, ok);
     if (!ok && why.empty()) why = "another rank failed";
     c->xch_ok = ok;
-    c->xch_seq = XCH_TEST_ROUNDS;                              // the self-test used sequence numbers 1..rounds
     if (!ok) xch_teardown(c);
 }
 
@@ -1579,11 +1828,15 @@ int msgw_comm_init(msgw_ctx *c, const void *id128, int rank, int nranks)
     // MSGW_EXCHANGE_ONLY=1: no RCCL communicator at all (single node, every coupled step must then be
     // able to take the persistent kernel); also the way two ranks can share ONE GPU in tests, which
     // RCCL refuses.  MSGW_EXCHANGE=0: never use the in-kernel exchange (always the all-reduce chain).
+    // MSGW_XCH_TRANSPORT=shm: skip the device-resident transport (host segment only).
     const char *eo = std::getenv("MSGW_EXCHANGE_ONLY");
     const bool exchange_only = eo && std::atoi(eo) != 0;
     const char *ex = std::getenv("MSGW_EXCHANGE");
     const bool want_exchange = exchange_only || !(ex && std::atoi(ex) == 0);
+    const char *tr = std::getenv("MSGW_XCH_TRANSPORT");
+    const int want_direct = !(tr && std::strcmp(tr, "shm") == 0);
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_status(c)) return rc;
     if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (!exchange_only) {
         if (!g_rccl.load()) return fail(c, MSGW_ERR_RCCL, "%s", g_rccl.load_error.c_str());
@@ -1600,9 +1853,12 @@ int msgw_comm_init(msgw_ctx *c, const void *id128, int rank, int nranks)
     // multi-GPU code path (reduce -> ncclAllReduce -> 1-row prologue) can be tested on a 1-GPU box
     if (const char *e = std::getenv("MSGW_FORCE_COLLECTIVE")) c->force_coll = std::atoi(e) != 0;
     std::string why;
-    if (want_exchange && (nranks > 1 || c->force_coll)) xch_setup(c, id128, why);
+    if (want_exchange && (nranks > 1 || c->force_coll)) xch_setup(c, id128, why, want_direct);
     else xch_teardown(c);
     c->cnt.exchange = c->xch_ok ? 1 : 0;
+    c->cnt.transport = c->xch_ok ? (c->xch_direct ? MSGW_TRANSPORT_DEVICE_IPC : MSGW_TRANSPORT_HOST_SHM)
+                                 : ((nranks > 1 || c->force_coll) ? MSGW_TRANSPORT_RCCL : MSGW_TRANSPORT_NONE);
+    c->cnt.tenants = c->tenants;
     if (exchange_only && !c->xch_ok && nranks > 1)
         return fail(c, MSGW_ERR_RCCL, "MSGW_EXCHANGE_ONLY=1 but the node-level exchange could not be set up: %s", why.c_str());
     if (!c->xch_ok && !why.empty() && std::getenv("MSGW_VERBOSE"))
@@ -1631,6 +1887,7 @@ int msgw_counters(msgw_ctx *c, msgw_counters_t *out)
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->cnt.last_step_ms = ms;
     }
+    if (int rc = check_status(c)) return rc;
     *out = c->cnt;
     return MSGW_OK;
 }

@@ -51,20 +51,29 @@ constexpr int PD_LOCAL = 96;             // ready[PD_LOCAL]: several ranks: flux
 constexpr int TICKET_STRIDE = 32;        // unsigned ints between two tickets: pollers and arrivers of different
                                          // groups never share a cache line
 
-// Node-level exchange: fine-grained host memory mapped by all ranks.  Read by the exchange
-// workgroup only, so it lives in device memory instead of widening every workgroup's arguments.
+// Node-level exchange of the rank rows.  Two transports, same protocol (sequence-numbered rows, rank-order sum):
+//  * direct (default when it passes its self-test): every rank owns a buffer in ITS OWN HBM that all ranks of the
+//    node have mapped through HIP IPC.  A rank writes its row into the slot it owns in EVERY rank's buffer (one
+//    posted write per peer over xGMI, nothing is read remotely), then its sequence number likewise; it polls and
+//    sums its LOCAL buffer only.
+//  * host segment (fallback): one POSIX shared-memory segment registered with every GPU (fine-grained host memory,
+//    reached over PCIe); rows and sequence numbers are written to and polled in the segment.
+// Read by the exchange workgroup only.
 struct XchArgs {
     int nranks, rank;
     int stride;                   // doubles per rank row (a multiple of 8)
-    int pad_;
-    double *rows;                 // [2][nranks][stride] rank rows, by parity of the sequence number
-    unsigned long long *flags;    // [nranks][8]  sequence number of the newest row a rank has published
+    int direct;                   // 1: device-resident transport (peer_rows / peer_flags are valid)
+    double *rows;                 // [2][nranks][stride] rank rows, by parity of the sequence number (local view)
+    unsigned long long *flags;    // [nranks][8]  sequence number of the newest row a rank has published (local view)
+    double *const *peer_rows;     // direct: [nranks] the `rows` of every rank's buffer as mapped in this process
+    unsigned long long *const *peer_flags;   // direct: [nranks] the `flags` of every rank's buffer
     unsigned long long seq;       // sequence number of this launch's flux 0, minus 1
     unsigned long long timeout_ticks;
 };
 
-struct PersistArgs {
-    StageArgs s;                  // rays, constants, static column tables; grp_size/row_stride
+template <typename T>
+struct PersistArgsT {
+    StageArgsT<T> s;              // rays, constants, static column tables; grp_size/row_stride
     int nsteps;
     int ngroups;                  // workgroups [g*grp_size, ...) form group g
     double *grp_part2;            // [2][workgroups][row_stride]   workgroup rows, by flux parity
@@ -84,7 +93,9 @@ struct PersistArgs {
     unsigned int opts;            // PERSIST_OPT_*
     int *status;                  // 0 ok, 1 a wait timed out
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
-    const struct XchArgs *xch;    // several ranks: the node-level exchange (device memory); else nullptr
+    int has_xch;                  // several ranks: the node-level exchange runs (one extra workgroup)
+    XchArgs xch;                  // ... with this transport (by value: the launch is not waited for, so nothing the
+                                  // kernel reads may live in host memory that the call could leave behind)
     ColIn cin;                    // canonical column at entry
     ColOut cout;                  // canonical column at exit (workgroup 0)
     double *dudz, *dvdz, *slu, *slv;    // derived tables at exit (workgroup 0)
@@ -92,6 +103,7 @@ struct PersistArgs {
     unsigned long long *pstamps;  // diagnostic build: [workgroups][PSTAMP_PASSES][4] wall-clock stamps
 #endif
 };
+typedef PersistArgsT<double> PersistArgs;
 #ifdef MSGW_STAMP
 constexpr int PSTAMP_PASSES = 16;
 #define PSTAMP(q, k) do { if (threadIdx.x == 0 && p.pstamps && (q) < (unsigned)PSTAMP_PASSES) \
@@ -147,19 +159,27 @@ __device__ __forceinline__ bool xch_wait_all(const u64_t *flags, int nranks, u64
     return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
 }
 
-// Node-level sum of one row per rank (see the header comment).  `mine` is this rank's value of
-// column `tid`; returns false after a time-out.  s_flag: an LDS word not used by other hand-offs.
-__device__ __forceinline__ bool xch_allsum(int nranks, int rank, int stride, double *rows, u64_t *flags, u64_t seq,
-                                           int *status, u64_t timeout_ticks, int ncols, int tid, int *s_flag,
+// Node-level sum of one row per rank (see XchArgs).  `mine` is this rank's value of column `tid`; returns false after
+// a time-out.  s_flag: an LDS word not used by other hand-offs.
+__device__ __forceinline__ bool xch_allsum(const XchArgs x, u64_t seq, int *status, int ncols, int tid, int *s_flag,
                                            double mine, double &tot)
 {
-    double *slot = rows + (size_t)(seq & 1ull) * nranks * stride;
-    if (tid < ncols) st_sys(slot + (size_t)rank * stride + tid, mine);
+    const size_t slot_off = (size_t)(seq & 1ull) * x.nranks * x.stride;
+    if (x.direct) {                                           // my row into the slot I own in every rank's buffer
+        if (tid < ncols)
+            for (int j = 0; j < x.nranks; ++j) st_sys(x.peer_rows[j] + slot_off + (size_t)x.rank * x.stride + tid, mine);
+    } else {
+        if (tid < ncols) st_sys(x.rows + slot_off + (size_t)x.rank * x.stride + tid, mine);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // system scope: every storing wave's row is out
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flags + 8 * rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (x.direct) {
+        if (tid < x.nranks) __hip_atomic_store(x.peer_flags[tid] + 8 * x.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        if (tid == 0) __hip_atomic_store(x.flags + 8 * x.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (tid < 64) {
-        const bool ok = xch_wait_all(flags, nranks, seq, status, timeout_ticks, tid);
+        const bool ok = xch_wait_all(x.flags, x.nranks, seq, status, x.timeout_ticks, tid);
         if (tid == 0) {
             if (!ok && status) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *s_flag = ok ? 1 : 0;
@@ -169,14 +189,15 @@ __device__ __forceinline__ bool xch_allsum(int nranks, int rank, int stride, dou
     if (!*s_flag) return false;
     tot = 0.0;
     if (tid < ncols)
-        for (int r = 0; r < nranks; ++r) tot = tot + ld_sys(slot + (size_t)r * stride + tid);   // rank order
+        for (int r = 0; r < x.nranks; ++r) tot = tot + ld_sys(x.rows + slot_off + (size_t)r * x.stride + tid);   // rank order
     return true;
 }
 
 // Wait until *counter >= target (one lane polls, bounded), then release the workgroup.  `seen` is
 // a value of the counter that lane 0 has already loaded (see persist_stage: the first poll is issued
 // BEFORE the tile loads, so its result does not wait for them -- memory returns in order).
-__device__ __forceinline__ bool persist_wait_seen(const PersistArgs p, unsigned int target, unsigned int seen,
+template <typename T>
+__device__ __forceinline__ bool persist_wait_seen(const PersistArgsT<T> p, unsigned int target, unsigned int seen,
                                                   int *s_flag, int tid, const unsigned int *counter)
 {
     if (tid == 0) {
@@ -212,7 +233,8 @@ __device__ __forceinline__ bool persist_wait_seen(const PersistArgs p, unsigned 
     return r != 0;
 }
 
-__device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int target, int *s_flag, int tid,
+template <typename T>
+__device__ __forceinline__ bool persist_wait(const PersistArgsT<T> p, unsigned int target, int *s_flag, int tid,
                                              const unsigned int *counter = nullptr)
 {
     if (!counter) counter = p.ready;
@@ -222,9 +244,10 @@ __device__ __forceinline__ bool persist_wait(const PersistArgs p, unsigned int t
 }
 
 // Second level: add the rows of group g (flux f) in row order into the group's row.
-__device__ __forceinline__ void persist_reduce_group(const PersistArgs p, int g, unsigned int f, int ncols, int tid)
+template <typename T>
+__device__ __forceinline__ void persist_reduce_group(const PersistArgsT<T> p, int g, unsigned int f, int ncols, int tid)
 {
-    const StageArgs a = p.s;
+    const StageArgsT<T> a = p.s;
     const int nb = p.nworkers;
     const int r0 = g * a.grp_size, r1 = min(nb, r0 + a.grp_size);
     const unsigned int par = f & 1u;
@@ -247,7 +270,8 @@ __device__ __forceinline__ void persist_reduce_group(const PersistArgs p, int g,
 }
 
 // Third level: the sum of the group sums of flux f, in group order (thread `tid` < ncols: its column).
-__device__ __forceinline__ double persist_sum_groups(const PersistArgs p, unsigned int f, int ncols, int tid)
+template <typename T>
+__device__ __forceinline__ double persist_sum_groups(const PersistArgsT<T> p, unsigned int f, int ncols, int tid)
 {
     double tot = 0.0;
     if (tid < ncols) {
@@ -265,18 +289,19 @@ __device__ __forceinline__ double persist_sum_groups(const PersistArgs p, unsign
 
 // Without reducer workgroups: the last arriver of the flux's last group forms ONE final row (so that every
 // workgroup reads 2*(ng-2) values instead of ngroups times that) and announces it.
-__device__ __forceinline__ void persist_reduce_final(const PersistArgs p, unsigned int f, int ncols, int tid)
+template <typename T>
+__device__ __forceinline__ void persist_reduce_final(const PersistArgsT<T> p, unsigned int f, int ncols, int tid)
 {
     const unsigned int par = f & 1u;
     const double tot = persist_sum_groups(p, f, ncols, tid);
     // several ranks: this is only the rank's row; the exchange workgroup turns it into the final one
-    double *dst = p.xch ? p.flux2 + 2 * ncols : p.flux2;
+    double *dst = p.has_xch ? p.flux2 + 2 * ncols : p.flux2;
     if (tid < ncols) st_agent(dst + (size_t)par * ncols + tid, tot);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for flux f+2
-        __hip_atomic_fetch_add(p.xch ? p.ready + PD_LOCAL : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(p.has_xch ? p.ready + PD_LOCAL : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -289,10 +314,11 @@ __device__ __forceinline__ void persist_reduce_final(const PersistArgs p, unsign
 // their wait loop -- the reduce chain then reacts only when a reducer happens to be waiting, picks up
 // ~10 us of polling latency and gates everybody (80 -> 88.6 us per step); and phase-staggering the
 // dispatch rounds by up to half a pass at launch (no effect: the offsets relax within a few passes).
-__device__ __forceinline__ void persist_publish(const PersistArgs p, const double *rows, int ncp, int *s_flag,
+template <typename T>
+__device__ __forceinline__ void persist_publish(const PersistArgsT<T> p, const double *rows, int ncp, int *s_flag,
                                                 int tid, unsigned int f)
 {
-    const StageArgs a = p.s;
+    const StageArgsT<T> a = p.s;
     const int ncols = 2 * ncp;
     const int b = blockIdx.x, nb = p.nworkers;
     const int g = b / a.grp_size, r0 = g * a.grp_size, r1 = min(nb, r0 + a.grp_size);
@@ -336,7 +362,8 @@ __device__ __forceinline__ void persist_publish(const PersistArgs p, const doubl
 // flux of the launch wait until the group's rows have all arrived and add them.  This takes ~6.5 us of serial L2 round
 // trips per pass off the LAST ARRIVER, which is the workgroup everybody else is waiting for
 // (tools/persist_timeline.py).  Each reducer polls its own ticket on its own cache line.
-__device__ __forceinline__ void persist_service(const PersistArgs p, int g, int *s_flag, int tid)
+template <typename T>
+__device__ __forceinline__ void persist_service(const PersistArgsT<T> p, int g, int *s_flag, int tid)
 {
     const int ncols = 2 * (p.s.ng - 2);
     const unsigned int nflux = 3u * (unsigned int)p.nsteps + 1u;
@@ -371,7 +398,8 @@ __device__ __forceinline__ void persist_service(const PersistArgs p, int g, int 
 
 // Column / exchange workgroup: wait until all group sums of flux f are there, add them (registers),
 // re-arm the counter.  Returns false after a time-out.
-__device__ __forceinline__ bool persist_take_groups(const PersistArgs p, unsigned int f, int ncols, int *s_flag,
+template <typename T>
+__device__ __forceinline__ bool persist_take_groups(const PersistArgsT<T> p, unsigned int f, int ncols, int *s_flag,
                                                     int tid, double &tot)
 {
     const unsigned int par = f & 1u;
@@ -385,11 +413,12 @@ __device__ __forceinline__ bool persist_take_groups(const PersistArgs p, unsigne
 
 // The exchange workgroup (several ranks only; owns no rays): for every flux of the launch, wait for
 // the rank's row, add the rows of all ranks (xch_allsum), publish the final row.
-__device__ __forceinline__ void persist_exchange(const PersistArgs p, int *s_flag, int tid)
+template <typename T>
+__device__ __forceinline__ void persist_exchange(const PersistArgsT<T> p, int *s_flag, int tid)
 {
     const int ncols = 2 * (p.s.ng - 2);
     const unsigned int nflux = 3u * (unsigned int)p.nsteps + 1u;
-    const XchArgs x = *p.xch;
+    const XchArgs x = p.xch;
     const double *flux_local = p.flux2 + 2 * ncols;
     for (unsigned int f = 0; f < nflux; ++f) {
         const unsigned int par = f & 1u;
@@ -401,9 +430,7 @@ __device__ __forceinline__ void persist_exchange(const PersistArgs p, int *s_fla
             if (tid < ncols) mine = ld_agent(flux_local + (size_t)par * ncols + tid);
         }
         double tot = 0.0;
-        if (!xch_allsum(x.nranks, x.rank, x.stride, x.rows, x.flags, x.seq + f + 1ull, p.status, x.timeout_ticks,
-                        ncols, tid, s_flag + 2 + par, mine, tot))
-            return;
+        if (!xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, s_flag + 2 + par, mine, tot)) return;
         if (tid < ncols) st_agent(p.flux2 + (size_t)par * ncols + tid, tot);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -412,19 +439,37 @@ __device__ __forceinline__ void persist_exchange(const PersistArgs p, int *s_fla
     }
 }
 
+template <typename T>
 struct PersistLds {
-    double4 *sh; double2 *rho2; double *xg, *gs, *rows;
+    typename Real<T>::quad_t *sh; typename Real<T>::pair_t *rho2; T *xg, *gs;
+    double *xgd, *rows;
+    double4 *shd;                                 // the shear table in float64 (== sh when T = double)
     double *cu, *cv, *cqu, *cqv, *crho, *cpg;     // column replica + static rhobar, pg [2][nc]
     double *F, *u, *v, *du, *dv;                  // scratch (aliases rows)
     int *flag;
 };
 
+// shear table {dudz, slope, dvdz, slope} from the shear columns in LDS: float64 into L.shd (what the column
+// workgroup publishes and writes back) and, for float32 rays, the packed float32 copy the rays interpolate in
+template <typename T>
+__device__ __forceinline__ void persist_pack_tables(const PersistLds<T> L, int ni, int tid)
+{
+    for (int i = tid; i < ni; i += BLOCK) {
+        const bool in = i < ni - 1;
+        const double4 t = make_double4(L.du[i], in ? column_slope(L.du, L.xgd, i) : 0.0,
+                                       L.dv[i], in ? column_slope(L.dv, L.xgd, i) : 0.0);
+        L.shd[i] = t;
+        if constexpr (!std::is_same<T, double>::value) L.sh[i] = Real<T>::quad((T)t.x, (T)t.y, (T)t.z, (T)t.w);
+    }
+}
+
 // column_q = RK stage `pstage` of column_{q-1} with the final row of flux F_{q-1}; `have` = this thread's
 // value of the row (column `tid`) when the caller holds it in registers, else it is loaded from flux2
-__device__ __forceinline__ void persist_column(const PersistArgs p, const PersistLds L, unsigned int q,
+template <typename T>
+__device__ __forceinline__ void persist_column(const PersistArgsT<T> p, const PersistLds<T> L, unsigned int q,
                                                int pstage, int tid, bool in_regs = false, double have = 0.0)
 {
-    const StageArgs a = p.s;
+    const StageArgsT<T> a = p.s;
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2, ncols = 2 * ncp;
     if (tid < ncols) {
         const int pp = tid / ncp, c = tid - pp * ncp;
@@ -438,17 +483,13 @@ __device__ __forceinline__ void persist_column(const PersistArgs p, const Persis
         double du, dv, un, vn, qu, qv;
         column_tendency(tid, ng, a.f0, a.dzg, 0, L.F, L.crho[tid], L.cpg[tid], L.cpg[nc + tid], L.cu[tid],
                         L.cv[tid], du, dv);
-        column_rk(pstage, a.dt, du, dv, L.cu[tid], L.cv[tid], L.cqu[tid], L.cqv[tid], un, vn, qu, qv);
+        column_rk(pstage, a.dtc, du, dv, L.cu[tid], L.cv[tid], L.cqu[tid], L.cqv[tid], un, vn, qu, qv);
         L.cu[tid] = un; L.cv[tid] = vn; L.cqu[tid] = qu; L.cqv[tid] = qv;
     }
     __syncthreads();
     column_shear(tid, BLOCK, ng, a.dzg, L.cu, L.cv, L.du, L.dv);
     __syncthreads();
-    for (int i = tid; i < ni; i += BLOCK) {
-        const bool in = i < ni - 1;
-        L.sh[i] = make_double4(L.du[i], in ? column_slope(L.du, L.xg, i) : 0.0,
-                               L.dv[i], in ? column_slope(L.dv, L.xg, i) : 0.0);
-    }
+    persist_pack_tables(L, ni, tid);
     __syncthreads();
 }
 
@@ -457,14 +498,15 @@ __device__ __forceinline__ void persist_column(const PersistArgs p, const Persis
 // the column replica in LDS, derive the shear table the rays interpolate in, publish the table and
 // release the pass.  The ray workgroups then load 3.2 KB and pass one barrier instead of each
 // repeating the update (a poll, a row load, five barriers: 3.7 us on the critical path per pass).
-__device__ __forceinline__ void persist_column_wg(const PersistArgs p, const PersistLds L, int tid)
+template <typename T>
+__device__ __forceinline__ void persist_column_wg(const PersistArgsT<T> p, const PersistLds<T> L, int tid)
 {
     const int ng = p.s.ng, ni = ng - 2, nc = ng - 1;
     const unsigned int nflux = 3u * (unsigned int)p.nsteps;      // the flux of the final state is unused
     const int ncols = 2 * (ng - 2);
     for (unsigned int f = 0; f < nflux; ++f) {
         // pass q = f+1 is RK stage q % 3, column stage (q+2) % 3 = f % 3
-        if (p.xch) {                                           // several ranks: the exchange workgroup's final row
+        if (p.has_xch) {                                       // several ranks: the exchange workgroup's final row
             if (!persist_wait(p, f + 1u, L.flag, tid, p.ready + PD_ROW)) return;
             persist_column(p, L, f + 1u, (int)(f % 3u), tid);
         } else {                                               // one rank: add the reducers' group sums right here
@@ -473,7 +515,7 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgs p, const Per
             persist_column(p, L, f + 1u, (int)(f % 3u), tid, true, tot);
         }
         double *tab = p.shtab + (size_t)(f & 1u) * 4 * ni;
-        const double *src = reinterpret_cast<const double *>(L.sh);
+        const double *src = reinterpret_cast<const double *>(L.shd);
         for (int i = tid; i < 4 * ni; i += BLOCK) st_agent(tab + i, src[i]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -484,25 +526,25 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgs p, const Per
         p.cout.uu[i] = L.cu[i]; p.cout.vv[i] = L.cv[i]; p.cout.q_uu[i] = L.cqu[i]; p.cout.q_vv[i] = L.cqv[i];
     }
     for (int i = tid; i < ni; i += BLOCK) {
-        const double4 t = L.sh[i];
+        const double4 t = L.shd[i];
         p.dudz[i] = t.x; p.dvdz[i] = t.z;
         if (i < ni - 1) { p.slu[i] = t.y; p.slv[i] = t.w; }
     }
 }
 
-template <int STAGE, bool SAT, bool FVEC, bool DIRECT, int NRES>
-__device__ __forceinline__ bool persist_stage(const PersistArgs p, const PersistLds L, unsigned int q,
+template <typename T, int STAGE, bool SAT, bool FVEC, bool DIRECT, int NRES, bool RL>
+__device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const PersistLds<T> L, unsigned int q,
                                               long long start, long long end, int tid, int wave, int lane,
-                                              TileRegs (&res)[NRES > 0 ? NRES : 1])
+                                              TileRegs<T> (&res)[NRES > 0 ? NRES : 1])
 {
-    const StageArgs a = p.s;
+    const StageArgsT<T> a = p.s;
     const int ncp = a.ng - 2;
     // Opaque copies: without them the three inlined stage bodies share (CSE) every per-array tile
     // address and keep ~60 VGPRs of 64-bit addresses alive across the whole step.
     asm volatile("" : "+s"(start));
     asm volatile("" : "+v"(tid));
     PSTAMP(q, 0);
-    TileRegs cur;
+    TileRegs<T> cur;
     // Lane 0's first poll of `ready` is issued before its tile loads: returns are in order, so the
     // poll's result is there after one round trip while the tile's 11 loads are still in flight.
     unsigned int seen = 0;
@@ -510,13 +552,13 @@ __device__ __forceinline__ bool persist_stage(const PersistArgs p, const Persist
     // `start` is the first STREAMED ray (the NRES resident tiles before it never leave the registers); a
     // workgroup may have no streamed tile at all (workgroup-uniform test, the arrays are padded by one tile only)
     constexpr bool CGMEM = NRES > 0 && !SAT && !DIRECT;         // see process_tiles
-    if (NRES == 0 || start < end) load_tile<STAGE, SAT, FVEC, true, DIRECT, CGMEM>(cur, a, start, tid, end);
+    if (NRES == 0 || start < end) load_tile<T, STAGE, SAT, FVEC, true, DIRECT, CGMEM>(cur, a, start, tid, end);
     if (q > 0) {
         if (!persist_wait_seen(p, q, seen, L.flag, tid, p.ready)) return false;
         if (p.nservice) {                                      // the column workgroup has published this pass's table
             const double *tab = p.shtab + (size_t)((q - 1u) & 1u) * 4 * (a.ng - 2);
-            double *dst = reinterpret_cast<double *>(L.sh);
-            for (int i = tid; i < 4 * (a.ng - 2); i += BLOCK) dst[i] = ld_agent(tab + i);
+            T *dst = reinterpret_cast<T *>(L.sh);
+            for (int i = tid; i < 4 * (a.ng - 2); i += BLOCK) dst[i] = (T)ld_agent(tab + i);
             __syncthreads();
         } else {
             persist_column(p, L, q, (STAGE + 2) % 3, tid);
@@ -526,8 +568,8 @@ __device__ __forceinline__ bool persist_stage(const PersistArgs p, const Persist
     for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
     __syncthreads();
     int wmin = INT_MAX, wmax = INT_MIN;
-    const StageLds SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
-    process_tiles<STAGE, SAT, FVEC, true, DIRECT, 2, true, NRES>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax, &res);
+    const StageLds<T> SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
+    process_tiles<T, STAGE, SAT, FVEC, true, DIRECT, 2, true, NRES, RL>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax, &res);
     PSTAMP(q, 2);
     persist_publish(p, L.rows, ncp, L.flag, tid, q + 1u);     // this pass produced state_{q+1}: publish F_{q+1}
     PSTAMP(q, 3);
@@ -536,24 +578,28 @@ __device__ __forceinline__ bool persist_stage(const PersistArgs p, const Persist
 
 // NRES > 0: the first NRES tiles of every ray workgroup are RESIDENT IN REGISTERS for the whole launch
 // (loaded once, written back once): at 2 workgroups per CU a lane has 256 VGPRs, enough for two tiles'
-// state (9 arrays x 2 rays x 2 VGPRs each) beside the working set, and the HBM traffic of a pass drops by
+// state (9 arrays x 16 B per lane each) beside the working set, and the HBM traffic of a pass drops by
 // NRES / tiles_per_block.  Same tile order, same arithmetic: the deposit order is still ray order.
-template <bool SAT, bool FVEC, bool DIRECT, int NRES = 0>
-__global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const PersistArgs p)
+// RL: the MSGW_RELAUNCH extension (BASELINE config 5) as a compile-time variant, so that the reference-parity
+// kernels carry none of its registers.
+template <typename T, bool SAT, bool FVEC, bool DIRECT, int NRES = 0, bool RL = false>
+__global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const PersistArgsT<T> p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const StageArgs a = p.s;
+    constexpr int TILE = Real<T>::TILE;
+    constexpr int RPT = Real<T>::RPT;
+    const StageArgsT<T> a = p.s;
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
-    PersistLds L;
-    L.sh = reinterpret_cast<double4 *>(lds);
-    L.rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);
-    L.xg = lds + 4 * ni + 2 * nc;
-    L.gs = L.xg + ni;
-    L.rows = L.gs + nc;
+    const StageCarve<T> C(lds, ng);
+    PersistLds<T> L;
+    L.sh = C.sh; L.rho2 = C.rho2; L.xg = C.xg; L.gs = C.gs; L.xgd = C.xgd; L.rows = C.rows;
     double *colrep = L.rows + WAVES * 2 * ncp;
     L.cu = colrep; L.cv = L.cu + nc; L.cqu = L.cv + nc; L.cqv = L.cqu + nc; L.crho = L.cqv + nc; L.cpg = L.crho + nc;
     L.flag = reinterpret_cast<int *>(L.cpg + 2 * nc);
-    L.F = L.rows; L.u = L.F + 2 * ng; L.v = L.u + nc; L.du = L.v + nc; L.dv = L.du + ni;
+    if constexpr (std::is_same<T, double>::value) L.shd = reinterpret_cast<double4 *>(L.sh);
+    else                                                       // 32 bytes of flags, then [ni] double4 (32-B aligned)
+        L.shd = reinterpret_cast<double4 *>((reinterpret_cast<uintptr_t>(L.flag + 8) + 31) & ~(uintptr_t)31);
+    L.F = C.F; L.u = C.u; L.v = C.v; L.du = C.du; L.dv = C.dv;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #ifdef MSGW_STAMP
@@ -576,21 +622,16 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
     // a CU finishes last -- the oldest instead of the youngest -- and leaves the period unchanged: the
     // CU's drain time plus the last workgroup's hand-off is what counts.)
 
-    for (int i = tid; i < ni; i += BLOCK) L.xg[i] = a.c.xg[i];
+    stage_xg(C, a.c, ni, tid);
+    stage_rho(C, a.c, nc, tid, true);
     for (int i = tid; i < nc; i += BLOCK) {
-        L.gs[i] = a.c.grids[i];
-        L.rho2[i] = make_double2(a.c.rhobar[i], (i < nc - 1) ? a.c.slrho[i] : 0.0);
         L.cu[i] = p.cin.uu[i]; L.cv[i] = p.cin.vv[i]; L.cqu[i] = 0.0; L.cqv[i] = 0.0;
         L.crho[i] = a.c.rhobar[i]; L.cpg[i] = a.pg[i]; L.cpg[nc + i] = a.pg[nc + i];
     }
     __syncthreads();
     column_shear(tid, BLOCK, ng, a.dzg, L.cu, L.cv, L.du, L.dv);
     __syncthreads();
-    for (int i = tid; i < ni; i += BLOCK) {
-        const bool in = i < ni - 1;
-        L.sh[i] = make_double4(L.du[i], in ? column_slope(L.du, L.xg, i) : 0.0,
-                               L.dv[i], in ? column_slope(L.dv, L.xg, i) : 0.0);
-    }
+    persist_pack_tables(L, ni, tid);
     __syncthreads();
     if (role >= 0) {
         persist_column_wg(p, L, tid);
@@ -601,30 +642,30 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
     {
         for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
         __syncthreads();
-        const StageLds SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
+        const StageLds<T> SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
         // (with resident tiles: also leaves cg_rr of the initial state of the streamed tiles in memory)
-        deposit_pass<FVEC, 2, (NRES > 0 && !SAT && !DIRECT)>(a, SL, start, end, tid, wave, lane, start + (long long)NRES * TILE);
+        deposit_pass<T, FVEC, 2, (NRES > 0 && !SAT && !DIRECT)>(a, SL, start, end, tid, wave, lane, start + (long long)NRES * TILE);
         persist_publish(p, L.rows, ncp, L.flag, tid, 0u);
     }
     // resident tiles: everything a stage may read (stage 2 of the DIRECT variant reads the most); lanes
     // beyond the workgroup's rays hold inert values and are never deposited or stored
-    TileRegs res[NRES > 0 ? NRES : 1];
+    TileRegs<T> res[NRES > 0 ? NRES : 1];
     if constexpr (NRES > 0) {
 #pragma unroll
         for (int i = 0; i < NRES; ++i) {
             const long long base = start + (long long)i * TILE;
             if (base < end) {                                  // workgroup-uniform
-                load_tile<2, SAT, FVEC, true, DIRECT>(res[i], a, base, tid, end);
+                load_tile<T, 2, SAT, FVEC, true, DIRECT>(res[i], a, base, tid, end);
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {                  // cg_rr of the initial state (carried from then on)
-                    const double f = FVEC ? res[i].ff[r] : a.f_uni;
-                    double kh2, m2, vk2, om;
+                for (int r = 0; r < RPT; ++r) {                // cg_rr of the initial state (carried from then on)
+                    const T f = FVEC ? res[i].ff[r] : a.f_uni;
+                    T kh2, m2, vk2, om;
                     dispersion(res[i].kk[r], res[i].ll[r], res[i].mm[r], f * f, a.bvf2, kh2, m2, vk2, om, res[i].cg[r]);
                 }
             } else {
-                TileRegs z{};
-                z.mm[0] = z.mm[1] = 1.0; z.kk[0] = z.kk[1] = 1.0; z.drr[0] = z.drr[1] = 1.0; z.pvf[0] = z.pvf[1] = 1.0;
-                z.v0 = z.v1 = false;
+                TileRegs<T> z{};
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) { z.mm[r] = T(1); z.kk[r] = T(1); z.drr[r] = T(1); z.pvf[r] = T(1); z.v[r] = false; }
                 res[i] = z;
             }
         }
@@ -632,20 +673,20 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
     const long long sstart = start + (long long)NRES * TILE;    // first streamed ray
     unsigned int q = 0;
     for (int step = 0; step < p.nsteps; ++step) {
-        if (!persist_stage<0, SAT, FVEC, DIRECT, NRES>(p, L, q, sstart, end, tid, wave, lane, res)) return;
+        if (!persist_stage<T, 0, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res)) return;
         ++q;
-        if (!persist_stage<1, SAT, FVEC, DIRECT, NRES>(p, L, q, sstart, end, tid, wave, lane, res)) return;
+        if (!persist_stage<T, 1, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res)) return;
         ++q;
-        if (!persist_stage<2, SAT, FVEC, DIRECT, NRES>(p, L, q, sstart, end, tid, wave, lane, res)) return;
+        if (!persist_stage<T, 2, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res)) return;
         ++q;
     }
     if constexpr (NRES > 0) {                                  // write the resident tiles back
 #pragma unroll
         for (int i = 0; i < NRES; ++i) {
-            if (res[i].v0) {
-                store2(a.r.rr, res[i].off, res[i].rr);
-                store2(a.r.mm, res[i].off, res[i].mm);
-                if (SAT || DIRECT) store2(a.r.dens, res[i].off, res[i].dens);
+            if (res[i].v[0]) {
+                storev(a.r.rr, res[i].off, res[i].rr);
+                storev(a.r.mm, res[i].off, res[i].mm);
+                if (SAT || DIRECT || RL) storev(a.r.dens, res[i].off, res[i].dens);
             }
         }
     }
@@ -658,50 +699,17 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
         p.cout.uu[i] = L.cu[i]; p.cout.vv[i] = L.cv[i]; p.cout.q_uu[i] = L.cqu[i]; p.cout.q_vv[i] = L.cqv[i];
     }
     for (int i = tid; i < ni; i += BLOCK) {
-        const double4 t = L.sh[i];
+        const double4 t = L.shd[i];
         p.dudz[i] = t.x; p.dvdz[i] = t.z;
         if (i < ni - 1) { p.slu[i] = t.y; p.slv[i] = t.w; }
     }
 }
 
-// Self-test of the node-level exchange, run once by every rank when the communicator is set up:
-// `rounds` node-level sums of known rows through the very code path of the persistent kernel.  A rank
-// that cannot see the others' rows (or sees them out of order) reports 0 and the host side falls
-// back to the all-reduce launch chain on every rank.
+// arguments of the exchange self-test (k_xch_selftest, misc_kernels.h)
 struct XchTestArgs {
-    int nranks, rank, stride, rounds;
-    double *rows;
-    unsigned long long *flags;
-    unsigned long long timeout_ticks;
+    XchArgs x;                    // seq: the first round's sequence number minus 1
+    int rounds;
     int *result;                  // 1 = every round summed to the expected value
 };
-
-__device__ __forceinline__ double xch_test_value(int rank, int round, int col)
-{
-    return (double)(rank + 1) * 1048576.0 + (double)round * 1024.0 + (double)col + 0.5;
-}
-
-__global__ void __launch_bounds__(BLOCK) k_xch_selftest(const XchTestArgs t)
-{
-    __shared__ int s_flag[4];
-    const int tid = threadIdx.x;
-    const int ncols = min(t.stride, BLOCK);
-    int good = 1;
-    for (int round = 1; round <= t.rounds; ++round) {
-        double tot = 0.0;
-        if (!xch_allsum(t.nranks, t.rank, t.stride, t.rows, t.flags, (u64_t)round, nullptr, t.timeout_ticks, ncols,
-                        tid, s_flag + (round & 1), xch_test_value(t.rank, round, tid), tot)) {
-            good = 0;
-            break;
-        }
-        if (tid < ncols) {
-            double want = 0.0;
-            for (int r = 0; r < t.nranks; ++r) want = want + xch_test_value(r, round, tid);
-            if (tot != want) good = 0;
-        }
-    }
-    const int all_good = __syncthreads_and(good);
-    if (tid == 0) *t.result = all_good ? 1 : 0;
-}
 
 }   // namespace msgw

@@ -1,66 +1,69 @@
 // Device code of the ray-propagation path, written for CDNA4 / gfx950 only
 // (wave64, DPP cross-lane reduction, LDS-staged column, 16-B/lane coalesced
 // SoA loads).  Compiled with -ffp-contract=off: every expression below is in
-// the reference's (numpy's) evaluation order so that per-ray results are
-// bit-comparable with lib/libprop.py.  Citations are reference file:line.
+// the reference's (numpy's) evaluation order so that, with T = double, per-ray
+// results are bit-comparable with lib/libprop.py.  T = float is the throughput
+// mode of BASELINE config 5 (same formulas in float32; flux rows, their reduction
+// and the mean-flow column stay float64).  Citations are reference file:line.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <climits>
 #include <cstdint>
 #include "column_math.h"
+#include "real.h"
 
 namespace msgw {
 
-constexpr int BLOCK = 256;           // 4 wavefronts
-constexpr int WAVES = BLOCK / 64;
-constexpr int RPT = 2;               // rays per lane -> 16-B global accesses
-constexpr int TILE = BLOCK * RPT;    // rays per workgroup iteration
 constexpr int SPAN_MAX = 8;          // widest per-wave level span on the shuffle path
 constexpr int COL_BLOCK = 1024;      // the column kernel is one workgroup
 constexpr int FUSE_ROWS = 16;        // most dense flux rows the fused prologue adds up (= reduce-1 groups)
 
-struct RayPtrs {
-    double *dens, *rr, *mm;                        // evolving slots 0, 3, 7
-    const double *drr, *kk, *ll, *dmm;             // frozen slots 4, 5, 6, 8 (HPROP off)
-    const double *vol;                             // |dkk*dll*dmm|            (:137)
-    const double *fray;                            // 2*Omega*sin(phi) per ray (:382)
-    const double *pvf;                             // dkk*dll*(rr_mm_area/drr) (:594, :599)
-    double *q_rr, *q_mm, *q_dens;                  // low-storage RK registers
-    double *rr0, *mm0;                             // start-of-step copies (direct saturation)
-    const double *src_dens, *src_rr, *src_mm;      // EXTENSION: source values for MSGW_RELAUNCH
-    double *cg;                                    // cg_rr of the current state (persistent kernel with resident
+template <typename T>
+struct RayPtrsT {
+    T *dens, *rr, *mm;                             // evolving slots 0, 3, 7
+    const T *drr, *kk, *ll, *dmm;                  // frozen slots 4, 5, 6, 8 (HPROP off)
+    const T *vol;                                  // |dkk*dll*dmm|            (:137)
+    const T *fray;                                 // 2*Omega*sin(phi) per ray (:382)
+    const T *pvf;                                  // dkk*dll*(rr_mm_area/drr) (:594, :599)
+    T *q_rr, *q_mm, *q_dens;                       // low-storage RK registers
+    T *rr0, *mm0;                                  // start-of-step copies (direct saturation)
+    const T *src_dens, *src_rr, *src_mm;           // EXTENSION: source values for MSGW_RELAUNCH
+    T *cg;                                         // cg_rr of the current state (persistent kernel with resident
                                                    // tiles: carried from the pass that produced the state)
 };
+typedef RayPtrsT<double> RayPtrs;
 
-struct ColPtrs {
+struct ColPtrs {                                   // the column is float64 in both modes
     const double *xg;                              // grid[1:-1], ni = ng-2
     const double *dudz, *dvdz;                     // first differences on xg (:352-353)
     const double *slu, *slv;                       // np.interp slopes, ni-1
     const double *grids, *rhobar, *slrho;          // nc = ng-1 (slopes nc-1)
 };
 
-struct StageArgs {
+template <typename T>
+struct StageArgsT {
     long long n;
     int ng;
     int tiles_per_block;  // ceil(rays_per_block / TILE)
     int fixed_steps;      // k_ray_step_fixed: RK3 steps per launch (rays are independent: state stays in registers)
     int relaunch;         // EXTENSION (MSGW_RELAUNCH): recycle rays that left the column or broke, after stage 2
-    double z_bot, z_top, relaunch_frac;
+    T z_bot, z_top, relaunch_frac;
     long long rays_per_block;   // contiguous rays owned by a workgroup (multiple of 16: 128-B aligned
                           // starts); chosen so that the workgroups divide evenly over the CUs
-    double dt;
-    double bvf2;          // bvf**2
-    double f_uni;         // per-ray f when it is the same for every ray
-    double f0sq;          // (2*Omega*sin(phi0))**2, config latitude (:589, :597)
+    T dt;
+    double dtc;           // dt of the mean-flow update (float64 in both modes)
+    T bvf2;               // bvf**2
+    T f_uni;              // per-ray f when it is the same for every ray
+    T f0sq;               // (2*Omega*sin(phi0))**2, config latitude (:589, :597)
     int same_f;           // f_uni*f_uni == f0sq  -> omh == om
-    double sat_c;         // kappa**2 * .5
-    double sat_rr_div;    // 1.0 (driver quirk raytracer.py:184) or dt
-    double xg0, inv_dzg;  // index guess on xg
-    double gs0, inv_dzs;  // index guess on grids
-    double xg_last, gs_last;   // last abscissa of each table (first = xg0 / gs0)
-    double dzs;           // grids[1]-grids[0]  (:123 with G = grids)
+    T sat_c;              // kappa**2 * .5
+    T sat_rr_div;         // 1.0 (driver quirk raytracer.py:184) or dt
+    T xg0, inv_dzg;       // index guess on xg
+    T gs0, inv_dzs;       // index guess on grids
+    T xg_last, gs_last;   // last abscissa of each table (first = xg0 / gs0)
+    T dzs;                // grids[1]-grids[0]  (:123 with G = grids)
     int mk_ok;            // RN(1/dzs) usable for the exact constant division (see div_const)
-    RayPtrs r;
+    RayPtrsT<T> r;
     ColPtrs c;
     double *partial;      // [blocks][2][ng-2] per-workgroup flux rows
     int *ranges;          // [blocks][2] touched level range of each row
@@ -87,6 +90,7 @@ struct StageArgs {
     unsigned long long *stamps;   // diagnostic build only: [blocks][8] wall-clock stamps
 #endif
 };
+typedef StageArgsT<double> StageArgs;
 #ifdef MSGW_STAMP
 #define MSGW_STAMP_AT(k) do { if (threadIdx.x == 0 && a.stamps) a.stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 #else
@@ -105,11 +109,20 @@ __device__ __forceinline__ double dpp_f64(double v)
     int lo = __double2loint(v), hi = __double2hiint(v);
     return __hiloint2double(dpp_i32<CTRL>(hi), dpp_i32<CTRL>(lo));
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(dpp_i32<CTRL>(__float_as_int(v)));
+}
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane_f32(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 // Sum over the 64 lanes in a FIXED order (xor 1, xor 2, half-mirror, mirror
 // inside each 16-lane row, then the four rows): bit-reproducible, no LDS.
@@ -122,6 +135,16 @@ __device__ __forceinline__ double wave_sum(double v)
     v = v + dpp_f64<0x140>(v);    // row_mirror
     const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16);
     const double r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v = v + dpp_f32<0xB1>(v);
+    v = v + dpp_f32<0x4E>(v);
+    v = v + dpp_f32<0x141>(v);
+    v = v + dpp_f32<0x140>(v);
+    const float r0 = readlane_f32(v, 0), r1 = readlane_f32(v, 16);
+    const float r2 = readlane_f32(v, 32), r3 = readlane_f32(v, 48);
     return (r0 + r1) + (r2 + r3);
 }
 // Two sums at once (the two pseudo-momentum-flux components): v_permlane32_swap puts the
@@ -146,6 +169,21 @@ __device__ __forceinline__ void wave_sum2(double a, double b, double &ta, double
     ta = readlane_f64(v, 0);
     tb = readlane_f64(v, 32);
 }
+// float32 form of the same butterfly: one dword per value, and the DPP steps fold into v_add_f32_dpp
+// (about 10 instructions for both sums).  Same fixed order.
+__device__ __forceinline__ void wave_sum2(float a, float b, float &ta, float &tb)
+{
+    const u32x2_t s = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    float v = __uint_as_float(s.x) + __uint_as_float(s.y);
+    v = v + dpp_f32<0xB1>(v);
+    v = v + dpp_f32<0x4E>(v);
+    v = v + dpp_f32<0x141>(v);
+    v = v + dpp_f32<0x140>(v);
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    ta = readlane_f32(v, 0);
+    tb = readlane_f32(v, 32);
+}
 __device__ __forceinline__ int wave_min(int v)
 {
     v = min(v, dpp_i32<0xB1>(v));
@@ -165,24 +203,6 @@ __device__ __forceinline__ int wave_max(int v)
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-// ------------------------------------------------------------------ global access
-// Every per-ray array is allocated and initialised up to a whole number of tiles (the host pads
-// with inert rays), so all accesses are UNCONDITIONAL 16-B vector accesses: a conditional
-// load makes hipcc branch around it and wait vmcnt(0) per load, which serialises the nine
-// streams of a tile into nine memory round trips (measured: 27 us vs 16 us per launch).
-// Addressing: uniform base pointer (SGPR pair) + ONE 32-bit byte offset shared by all SoA
-// arrays of a tile (global_load ... v_off, s[base] form) instead of a 64-bit VGPR address
-// per array: saves ~26 VGPRs and the address arithmetic.  Limits a context to 2^29 rays.
-__device__ __forceinline__ void load2(const double *p, unsigned int off, double (&out)[2])
-{
-    const double2 t = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(p) + off);   // 16 B per lane
-    out[0] = t.x; out[1] = t.y;
-}
-__device__ __forceinline__ void store2(double *p, unsigned int off, const double (&v)[2])
-{
-    *reinterpret_cast<double2 *>(reinterpret_cast<char *>(p) + off) = make_double2(v[0], v[1]);
-}
-
 // ------------------------------------------------------------------ np.interp on an LDS column
 // numpy's arr_interp (the arithmetic behind lib/libprop.py:355-356, :595):
 // end values outside [xp[0], xp[n-1]], fp[j] exactly when x == xp[j], otherwise
@@ -192,14 +212,14 @@ __device__ __forceinline__ void store2(double *p, unsigned int off, const double
 // fix-up against the real abscissae (so any monotone grid works; the fix-up loops run 0 times
 // away from cell boundaries).  `flat` != 0 means "take fp[j] as is" (outside the table, on its
 // last point, or exactly on a point).  NaN falls through to slope*(NaN - xj) + fp = NaN.
-struct Bracket { int j; int flat; double xj; };
-__device__ __forceinline__ Bracket interp_locate(double x, const double *xp, int n, double x_first,
-                                                 double x_last, double x0, double inv_dx)
+template <typename T> struct Bracket { int j; int flat; T xj; };
+template <typename T>
+__device__ __forceinline__ Bracket<T> interp_locate(T x, const T *xp, int n, T x_first, T x_last, T x0, T inv_dx)
 {
-    Bracket b;
+    Bracket<T> b;
     int j = (int)((x - x0) * inv_dx);
     j = min(max(j, 0), n - 2);
-    double xj = xp[j], xj1 = xp[j + 1];
+    T xj = xp[j], xj1 = xp[j + 1];
     while (x < xj && j > 0) { --j; xj1 = xj; xj = xp[j]; }
     while (x >= xj1 && j < n - 2) { ++j; xj = xj1; xj1 = xp[j + 1]; }
     const bool top = x >= x_last;                   // beyond or on the last point -> fp[n-1]
@@ -208,17 +228,19 @@ __device__ __forceinline__ Bracket interp_locate(double x, const double *xp, int
     b.flat = (top || x < x_first || x == xj) ? 1 : 0;
     return b;
 }
-__device__ __forceinline__ double interp_eval(double x, const Bracket &b, double fpj, double slj)
+template <typename T>
+__device__ __forceinline__ T interp_eval(T x, const Bracket<T> &b, T fpj, T slj)
 {
-    const double lin = slj * (x - b.xj) + fpj;
+    const T lin = slj * (x - b.xj) + fpj;
     return b.flat ? fpj : lin;
 }
 
-// numpy `.astype(int)` on x86-64 (lib/libprop.py:124-125) kept in the double
+// numpy `.astype(int)` on x86-64 (lib/libprop.py:124-125) kept in the floating-point
 // domain: truncation toward zero; NaN/inf/out-of-range behave as INT64_MIN.
-__device__ __forceinline__ double np_trunc_index(double t)
+template <typename T>
+__device__ __forceinline__ T np_trunc_index(T t)
 {
-    return (fabs(t) < 9.2233720368547758e18) ? trunc(t) : -9.3e18;
+    return (fabs(t) < T(9.2233720368547758e18)) ? trunc(t) : T(-9.3e18);
 }
 
 // Correctly rounded x / d for a wave-uniform constant d with c = RN(1/d) (Markstein):
@@ -226,15 +248,16 @@ __device__ __forceinline__ double np_trunc_index(double t)
 // significand is all ones (the host clears `ok` then).  3 VALU ops instead of the ~14 of an
 // IEEE fp64 division; bit-identical to numpy's `x / d` (checked on 2.4e8 samples on the CPU and
 // by the bit-exact parity tests).  Non-finite x goes through the plain product (inf stays inf).
-__device__ __forceinline__ double div_const(double x, double d, double c, int ok)
+template <typename T>
+__device__ __forceinline__ T div_const(T x, T d, T c, int ok)
 {
     if (!ok) return x / d;
-    const double q = x * c;
-    const double r = fma(-d, q, x);
-    const double q2 = fma(r, c, q);
-    return (fabs(x) < __builtin_huge_val()) ? q2 : q;
+    const T q = x * c;
+    const T r = fma(-d, q, x);
+    const T q2 = fma(r, c, q);
+    return (fabs(x) < real_inf<T>()) ? q2 : q;
 }
-constexpr double THIRD_RN = 1.0 / 3.0;
+template <typename T> __device__ __forceinline__ T third_rn() { return T(1) / T(3); }
 
 // ------------------------------------------------------------------ deposit (wave_projection)
 // lib/libprop.py:123-163.  Each lane holds RPT rays with extent [lo, up],
@@ -243,34 +266,36 @@ constexpr double THIRD_RN = 1.0 / 3.0;
 // the order is fixed), after a DPP reduction over the 64 lanes per level.  If
 // the wave's rays span more than SPAN_MAX levels (unsorted input) the lanes
 // fall back to LDS float64 atomics on the same private row.
-template <int NP>
-__device__ __forceinline__ void deposit_indices(double lo, double up, bool valid, double dz,
-                                                double cdz, int ok, int nzmax, int &nlo, int &nup)
+template <int NP, typename T>
+__device__ __forceinline__ void deposit_indices(T lo, T up, bool valid, T dz, T cdz, int ok, int nzmax, int &nlo, int &nup)
 {
-    const double nl = np_trunc_index(div_const(lo, dz, cdz, ok));               // :124
-    const double nu = np_trunc_index(div_const(up, dz, cdz, ok) + 1.);          // :125
-    const double nz = (double)nzmax;                         // :127
-    const bool ood = ((nl >= nz) && (nu >= nz)) || ((nl <= 0.0) && (nu <= 0.0));   // :129-130
-    nlo = (int)fmin(fmax(nl, 0.0), nz);                      // :133-134
-    nup = (int)fmin(fmax(nu, 0.0), nz);
+    const T nl = np_trunc_index(div_const(lo, dz, cdz, ok));               // :124
+    const T nu = np_trunc_index(div_const(up, dz, cdz, ok) + T(1));        // :125
+    const T nz = (T)nzmax;                                   // :127
+    const bool ood = ((nl >= nz) && (nu >= nz)) || ((nl <= T(0)) && (nu <= T(0)));   // :129-130
+    nlo = (int)fmin(fmax(nl, T(0)), nz);                     // :133-134
+    nup = (int)fmin(fmax(nu, T(0)), nz);
     if (ood || !valid) { nlo = 0; nup = 0; }                 // :135, :153-154
 }
 
-// NH > 0: the wave keeps its level sums in NH lane-distributed registers per payload (lane L of
+// NH > 0: the wave keeps its level sums in NH lane-distributed float64 registers per payload (lane L of
 // register h owns level 64*h + L), so the per-level result of the DPP reduction is added with a
 // predicated VALU add instead of a lane-0 LDS read-modify-write; flush_acc() folds them into the
 // wave's LDS row once per workgroup.  NH == 0 (columns with more than 128 levels): LDS RMW.
+// T = float: weights, payloads and the 64-lane butterfly are float32; everything from the per-level
+// wave sum onwards (registers, LDS rows, workgroup rows) is float64.
 #ifdef MSGW_DBG_LEVELS
 __device__ unsigned long long g_dbg_levels, g_dbg_tiles, g_dbg_wide;
 #endif
-template <int NP, int NH>
-__device__ __forceinline__ void deposit_tile(const double (&lo)[RPT], const double (&up)[RPT],
-                                             const int (&nlo)[RPT], const int (&nup)[RPT],
-                                             const double (&vol)[RPT], const double (&pay)[NP][RPT],
-                                             const double *sG, double dz, double cdz, int ok,
+template <int NP, int NH, typename T>
+__device__ __forceinline__ void deposit_tile(const T (&lo)[Real<T>::RPT], const T (&up)[Real<T>::RPT],
+                                             const int (&nlo)[Real<T>::RPT], const int (&nup)[Real<T>::RPT],
+                                             const T (&vol)[Real<T>::RPT], const T (&pay)[NP][Real<T>::RPT],
+                                             const T *sG, T dz, T cdz, int ok,
                                              double *row, int ncp, int lane, int &wmin, int &wmax,
                                              double (&acc)[NP][NH > 0 ? NH : 1])
 {
+    constexpr int RPT = Real<T>::RPT;
     int mylo = INT_MAX, myhi = INT_MIN;
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
@@ -293,25 +318,25 @@ __device__ __forceinline__ void deposit_tile(const double (&lo)[RPT], const doub
 #endif
     if (whi - wlo <= SPAN_MAX) {
         for (int c = wlo; c < whi; ++c) {                    // uniform trip count: all lanes stay
-            const double g0 = sG[c], g1 = sG[c + 1];         // LDS broadcast reads
-            double s[NP];
+            const T g0 = sG[c], g1 = sG[c + 1];              // LDS broadcast reads
+            T s[NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) s[p] = 0.0;
+            for (int p = 0; p < NP; ++p) s[p] = T(0);
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
                 const bool in = (c >= nlo[r]) && (c < nup[r]);
-                const double zmin = (g0 > lo[r]) ? g0 : lo[r];          // :157
-                const double zmax = (g1 < up[r]) ? g1 : up[r];          // :158
-                const double wv = div_const(fabs(zmax - zmin), dz, cdz, ok) * vol[r];   // :160, :162
+                const T zmin = (g0 > lo[r]) ? g0 : lo[r];               // :157
+                const T zmax = (g1 < up[r]) ? g1 : up[r];               // :158
+                const T wv = div_const(fabs(zmax - zmin), dz, cdz, ok) * vol[r];   // :160, :162
 #pragma unroll
-                for (int p = 0; p < NP; ++p) s[p] = s[p] + (in ? wv * pay[p][r] : 0.0);
+                for (int p = 0; p < NP; ++p) s[p] = s[p] + (in ? wv * pay[p][r] : T(0));
             }
-            double tsum[NP];
+            T tsum[NP];
             if (NP == 2) wave_sum2(s[0], s[NP - 1], tsum[0], tsum[NP - 1]);
             else tsum[0] = wave_sum(s[0]);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const double t = tsum[p];
+                const double t = (double)tsum[p];
                 if (NH > 0) {
                     const double mine = (lane == (c & 63)) ? t : 0.0;
 #pragma unroll
@@ -326,13 +351,13 @@ __device__ __forceinline__ void deposit_tile(const double (&lo)[RPT], const doub
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             for (int c = nlo[r]; c < nup[r]; ++c) {
-                const double g0 = sG[c], g1 = sG[c + 1];
-                const double zmin = (g0 > lo[r]) ? g0 : lo[r];
-                const double zmax = (g1 < up[r]) ? g1 : up[r];
-                const double wv = div_const(fabs(zmax - zmin), dz, cdz, ok) * vol[r];
+                const T g0 = sG[c], g1 = sG[c + 1];
+                const T zmin = (g0 > lo[r]) ? g0 : lo[r];
+                const T zmax = (g1 < up[r]) ? g1 : up[r];
+                const T wv = div_const(fabs(zmax - zmin), dz, cdz, ok) * vol[r];
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    __hip_atomic_fetch_add(&row[p * ncp + c], wv * pay[p][r], __ATOMIC_RELAXED,
+                    __hip_atomic_fetch_add(&row[p * ncp + c], (double)(wv * pay[p][r]), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
@@ -385,9 +410,9 @@ __device__ __forceinline__ void flush_rows(const double *rows, int ncp, int *s_r
 // (agent scope) and adds the group's rows in row order -- independent of arrival order, so the
 // result is bitwise reproducible.  Protocol: cdna_hip_programming.md Guideline 16 / split-K
 // recipe (sc1 payload + drained vmcnt + barrier + relaxed agent fetch_add; consumer acquire).
-template <int NP>
+template <int NP, typename T>
 __device__ __forceinline__ void flush_rows_group(const double *rows, int ncp, int *s_flag, double *s_scr,
-                                                 int tid, const StageArgs a)
+                                                 int tid, const StageArgsT<T> a)
 {
     typedef unsigned long long u64;
     const int ncols = NP * ncp;
@@ -482,9 +507,8 @@ __device__ __forceinline__ void flush_rows_group(const double *rows, int ncp, in
 // ------------------------------------------------------------------ dispersion
 // omega :383 and cg_rr :445-448 sharing sub-expressions (numpy recomputes the
 // identical values; sharing them is bit-neutral).
-__device__ __forceinline__ void dispersion(double kk, double ll, double mm, double f2, double bvf2,
-                                           double &kh2, double &m2, double &vk2, double &om,
-                                           double &cgr)
+template <typename T>
+__device__ __forceinline__ void dispersion(T kk, T ll, T mm, T f2, T bvf2, T &kh2, T &m2, T &vk2, T &om, T &cgr)
 {
     kh2 = kk * kk + ll * ll;
     m2 = mm * mm;
@@ -494,8 +518,8 @@ __device__ __forceinline__ void dispersion(double kk, double ll, double mm, doub
 }
 
 // saturation cap :601 (rho_f already interpolated)
-__device__ __forceinline__ double sat_cap(double sat_c, double rho_f, double omh, double bvf2,
-                                          double mm_f, double f0sq)
+template <typename T>
+__device__ __forceinline__ T sat_cap(T sat_c, T rho_f, T omh, T bvf2, T mm_f, T f0sq)
 {
     return sat_c * rho_f * omh * bvf2 / (mm_f * mm_f) / (omh * omh - f0sq);
 }
@@ -506,55 +530,94 @@ __device__ __forceinline__ double sat_cap(double sat_c, double rho_f, double omh
 // stage's INPUT state.  STAGE 3: tendencies only, written to the q arrays
 // (single-RHS probe).  DIRECT: the driver's post-step saturation
 // (raytracer.py:182-188) fused into stage 2 (stage 0 keeps rr, mm copies).
-// Registers of one tile (2 rays per lane) -- loaded one tile ahead of use.
+// Registers of one tile (RPT rays per lane) -- loaded one tile ahead of use.
+template <typename T>
 struct TileRegs {
-    double rr[2], mm[2], kk[2], ll[2], dens[2], drr[2], vol[2], ff[2], pvf[2];
-    double qr[2], qm[2], qd[2], rr0[2], mm0[2];
-    double cg[2];         // resident tiles only: cg_rr of the current state (see tile_body.inc)
-    unsigned int off;     // byte offset of this lane's ray pair in every SoA array
-    bool v0, v1;
+    static constexpr int RPT = Real<T>::RPT;
+    T rr[RPT], mm[RPT], kk[RPT], ll[RPT], dens[RPT], drr[RPT], vol[RPT], ff[RPT], pvf[RPT];
+    T qr[RPT], qm[RPT], qd[RPT], rr0[RPT], mm0[RPT];
+    T cg[RPT];            // resident tiles only: cg_rr of the current state (see tile_body.inc)
+    unsigned int off;     // byte offset of this lane's rays in every SoA array
+    bool v[RPT];          // ray index < end of the workgroup's range
 };
 
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool CGMEM = false>
-__device__ __forceinline__ void load_tile(TileRegs &t, const StageArgs a, long long base, int tid,
+template <typename T, int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool CGMEM = false>
+__device__ __forceinline__ void load_tile(TileRegs<T> &t, const StageArgsT<T> a, long long base, int tid,
                                           long long end)
 {
     // Loads are unconditional (the arrays are padded by a tile); rays at or beyond `end` belong to
     // the next workgroup or to the padding: they are computed on but neither deposited nor stored.
     constexpr bool NEED_RHO = SAT || (DIRECT && STAGE == 2);
-    const long long i0 = base + 2 * tid;
-    t.off = (unsigned int)(i0 * 8);
-    t.v0 = i0 < end;
-    t.v1 = i0 + 1 < end;
-    load2(a.r.rr, t.off, t.rr);
-    load2(a.r.mm, t.off, t.mm);
-    load2(a.r.kk, t.off, t.kk);
-    load2(a.r.ll, t.off, t.ll);
-    if (DEPOSIT || SAT || (DIRECT && STAGE == 2)) load2(a.r.dens, t.off, t.dens);
+    constexpr int RPT = Real<T>::RPT;
+    const long long i0 = base + RPT * tid;
+    t.off = (unsigned int)(i0 * (long long)sizeof(T));
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) t.v[r] = i0 + r < end;
+    loadv(a.r.rr, t.off, t.rr);
+    loadv(a.r.mm, t.off, t.mm);
+    loadv(a.r.kk, t.off, t.kk);
+    loadv(a.r.ll, t.off, t.ll);
+    if (DEPOSIT || SAT || (DIRECT && STAGE == 2)) loadv(a.r.dens, t.off, t.dens);
     if (DEPOSIT) {
-        load2(a.r.drr, t.off, t.drr);
-        load2(a.r.vol, t.off, t.vol);
+        loadv(a.r.drr, t.off, t.drr);
+        loadv(a.r.vol, t.off, t.vol);
     }
-    if (FVEC) load2(a.r.fray, t.off, t.ff);
-    if (NEED_RHO) load2(a.r.pvf, t.off, t.pvf);
+    if (FVEC) loadv(a.r.fray, t.off, t.ff);
+    if (NEED_RHO) loadv(a.r.pvf, t.off, t.pvf);
     if (STAGE == 1 || STAGE == 2) {
-        load2(a.r.q_rr, t.off, t.qr);
-        load2(a.r.q_mm, t.off, t.qm);
-        if (SAT) load2(a.r.q_dens, t.off, t.qd);
+        loadv(a.r.q_rr, t.off, t.qr);
+        loadv(a.r.q_mm, t.off, t.qm);
+        if (SAT) loadv(a.r.q_dens, t.off, t.qd);
     }
     if (DIRECT && STAGE == 2) {
-        load2(a.r.rr0, t.off, t.rr0);
-        load2(a.r.mm0, t.off, t.mm0);
+        loadv(a.r.rr0, t.off, t.rr0);
+        loadv(a.r.mm0, t.off, t.mm0);
     }
-    if (CGMEM) load2(a.r.cg, t.off, t.cg);
+    if (CGMEM) loadv(a.r.cg, t.off, t.cg);
 }
 
 // LDS views shared by the stage kernels
+template <typename T>
 struct StageLds {
-    const double4 *sh;      // [ni] {dudz, slope, dvdz, slope}
-    const double2 *rho2;    // [nc] {rhobar, slope}
-    const double *xg, *gs;  // abscissae: grid[1:-1] [ni], grids [nc]
+    const typename Real<T>::quad_t *sh;      // [ni] {dudz, slope, dvdz, slope}
+    const typename Real<T>::pair_t *rho2;    // [nc] {rhobar, slope}
+    const T *xg, *gs;       // abscissae: grid[1:-1] [ni], grids [nc]
     double *rows;           // [WAVES][2][ncp] per-wave flux rows
+};
+
+// Carve of the dynamic LDS of the stage kernels (and, with the column replica behind it, of the persistent
+// kernel): [sh: ni x {dudz, slu, dvdz, slv}] [rho2: nc x {rhobar, slope}] [xg: ni] [gs: nc] in T, then (T = float
+// only) a float64 copy of xg for the mean-flow arithmetic, then float64 [rows: WAVES x 2 x ncp] [rng].
+// The prologue scratch of the fused column update aliases the rows: F [2][ng], u, v [nc], du, dv [ni]
+// = 6*ng - 6 doubles inside 8*(ng - 2), which needs ng >= 5 (msgw_create enforces it).
+template <typename T>
+struct StageCarve {
+    typename Real<T>::quad_t *sh;
+    typename Real<T>::pair_t *rho2;
+    T *xg, *gs;
+    double *xgd;            // grid[1:-1] in float64 (== xg when T = double)
+    double *rows;
+    int *rng;
+    double *F, *u, *v, *du, *dv;
+    __device__ __forceinline__ StageCarve(void *lds, int ng)
+    {
+        const int ni = ng - 2, nc = ng - 1, ncp = ng - 2;
+        T *t = reinterpret_cast<T *>(lds);
+        sh = reinterpret_cast<typename Real<T>::quad_t *>(t);
+        rho2 = reinterpret_cast<typename Real<T>::pair_t *>(t + 4 * ni);
+        xg = t + 4 * ni + 2 * nc;
+        gs = xg + ni;
+        if constexpr (std::is_same<T, double>::value) {
+            xgd = xg;
+            rows = gs + nc;
+        } else {
+            const size_t bytes = (sizeof(T) * (size_t)(5 * ni + 3 * nc) + 15) & ~(size_t)15;
+            xgd = reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + bytes);
+            rows = xgd + ni;
+        }
+        rng = reinterpret_cast<int *>(rows + WAVES * 2 * ncp);
+        F = rows; u = F + 2 * ng; v = u + nc; du = v + nc; dv = du + ni;
+    }
 };
 
 // NOTE: the kernel-argument structs are passed BY VALUE into these inlined helpers.  By
@@ -568,17 +631,21 @@ struct StageLds {
 // deposit the state this stage has just PRODUCED, i.e. the next stage's wave_projection input.
 // Same values (cg_rr is re-evaluated from the same kk, ll, new mm the next stage will load), but the
 // flux of stage q+1 is then published one whole pass before it is needed.
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH, bool LAG = false, int NRES = 0,
+template <typename T, int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH, bool LAG = false, int NRES = 0,
           bool RELAUNCH = false>
-__device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds L, TileRegs &cur,
+__device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const StageLds<T> L, TileRegs<T> &cur,
                                               long long start, long long end, int tid, int wave,
                                               int lane, int &wmin, int &wmax,
-                                              TileRegs (*res)[NRES > 0 ? NRES : 1] = nullptr)
+                                              TileRegs<T> (*res)[NRES > 0 ? NRES : 1] = nullptr)
 {
+    constexpr int RPT = Real<T>::RPT;
+    constexpr int TILE = Real<T>::TILE;
+    typedef typename Real<T>::quad_t quad_t;
+    typedef typename Real<T>::pair_t pair_t;
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
-    const double4 *s_sh = L.sh;
-    const double2 *s_rho2 = L.rho2;
-    const double *s_xg = L.xg, *s_gs = L.gs;
+    const quad_t *s_sh = L.sh;
+    const pair_t *s_rho2 = L.rho2;
+    const T *s_xg = L.xg, *s_gs = L.gs;
     double *s_rows = L.rows;
     (void)s_rho2; (void)ng;
     // with resident tiles the kernel is FP64-VALU bound, not HBM bound: streamed tiles then carry cg_rr of
@@ -616,17 +683,19 @@ __device__ __forceinline__ void process_tiles(const StageArgs a, const StageLds 
 #undef TB_RESIDENT
 #undef TB_IDX
         MSGW_STAMP_AT(3 + 2 * (t & 1));
-        if (more) load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT, CGMEM>(cur, a, base + TILE, tid, end);
+        if (more) load_tile<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, CGMEM>(cur, a, base + TILE, tid, end);
     }
     if (DEPOSIT) flush_acc<2, NH>(s_rows + wave * 2 * ncp, ncp, lane, acc);
 }
 
 // Deposit-only pass over this workgroup's rays (no stores): wave_projection(var=0) of the CURRENT
 // state into the per-wave LDS rows.  Seeds the lagged-deposit pipeline of the persistent kernel.
-template <bool FVEC, int NH, bool CGSTORE = false>
-__device__ __forceinline__ void deposit_pass(const StageArgs a, const StageLds L, long long start, long long end,
+template <typename T, bool FVEC, int NH, bool CGSTORE = false>
+__device__ __forceinline__ void deposit_pass(const StageArgsT<T> a, const StageLds<T> L, long long start, long long end,
                                              int tid, int wave, int lane, long long cg_from = 0)
 {
+    constexpr int RPT = Real<T>::RPT;
+    constexpr int TILE = Real<T>::TILE;
     const int nc = a.ng - 1, ncp = a.ng - 2;
     int wmin = INT_MAX, wmax = INT_MIN;
     double acc[2][NH > 0 ? NH : 1];
@@ -637,54 +706,87 @@ __device__ __forceinline__ void deposit_pass(const StageArgs a, const StageLds L
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = start + (long long)t * TILE;
         if (base >= end) break;
-        const long long e0 = base + 2 * tid;
-        const unsigned int off = (unsigned int)(e0 * 8);
-        const bool valid[2] = {e0 < end, e0 + 1 < end};
-        double rr[2], mm[2], kk[2], ll[2], dens[2], drr[2], vol[2], ff[2];
-        load2(a.r.rr, off, rr); load2(a.r.mm, off, mm); load2(a.r.kk, off, kk); load2(a.r.ll, off, ll);
-        load2(a.r.dens, off, dens); load2(a.r.drr, off, drr); load2(a.r.vol, off, vol);
-        if (FVEC) load2(a.r.fray, off, ff);
-        double lo[2], up[2], pay[2][2], cg2[2];
-        int nlo[2], nup[2];
+        const long long e0 = base + RPT * tid;
+        const unsigned int off = (unsigned int)(e0 * (long long)sizeof(T));
+        bool valid[RPT];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const double f = FVEC ? ff[r] : a.f_uni;
-            double kh2, m2, vk2, om, cgr;
+        for (int r = 0; r < RPT; ++r) valid[r] = e0 + r < end;
+        T rr[RPT], mm[RPT], kk[RPT], ll[RPT], dens[RPT], drr[RPT], vol[RPT], ff[RPT];
+        loadv(a.r.rr, off, rr); loadv(a.r.mm, off, mm); loadv(a.r.kk, off, kk); loadv(a.r.ll, off, ll);
+        loadv(a.r.dens, off, dens); loadv(a.r.drr, off, drr); loadv(a.r.vol, off, vol);
+        if (FVEC) loadv(a.r.fray, off, ff);
+        T lo[RPT], up[RPT], pay[2][RPT], cg2[RPT];
+        int nlo[RPT], nup[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const T f = FVEC ? ff[r] : a.f_uni;
+            T kh2, m2, vk2, om, cgr;
             dispersion(kk[r], ll[r], mm[r], f * f, a.bvf2, kh2, m2, vk2, om, cgr);
             cg2[r] = cgr;
-            lo[r] = rr[r] - .5 * drr[r];
-            up[r] = rr[r] + .5 * drr[r];
+            lo[r] = rr[r] - T(.5) * drr[r];
+            up[r] = rr[r] + T(.5) * drr[r];
             deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, a.inv_dzs, a.mk_ok, nc - 2, nlo[r], nup[r]);
             pay[0][r] = cgr * kk[r] * dens[r];
             pay[1][r] = cgr * ll[r] * dens[r];
         }
-        if (CGSTORE && valid[0] && base >= cg_from) store2(a.r.cg, off, cg2);   // streamed tiles of the persistent kernel
-        deposit_tile<2, NH>(lo, up, nlo, nup, vol, pay, L.gs, a.dzs, a.inv_dzs, a.mk_ok,
-                            L.rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
+        if (CGSTORE && valid[0] && base >= cg_from) storev(a.r.cg, off, cg2);   // streamed tiles of the persistent kernel
+        deposit_tile<2, NH, T>(lo, up, nlo, nup, vol, pay, L.gs, a.dzs, a.inv_dzs, a.mk_ok,
+                               L.rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
     }
     flush_acc<2, NH>(L.rows + wave * 2 * ncp, ncp, lane, acc);
+}
+
+// stage the static tables of the column (float64 in global memory) into the LDS views
+template <typename T>
+__device__ __forceinline__ void stage_shear_table(const StageCarve<T> &C, const ColPtrs c, int ni, int tid)
+{
+    for (int i = tid; i < ni; i += BLOCK) {
+        const bool in = i < ni - 1;                      // the last point has no slope (never used)
+        C.sh[i] = Real<T>::quad((T)c.dudz[i], in ? (T)c.slu[i] : T(0), (T)c.dvdz[i], in ? (T)c.slv[i] : T(0));
+    }
+}
+template <typename T>
+__device__ __forceinline__ void stage_xg(const StageCarve<T> &C, const ColPtrs c, int ni, int tid)
+{
+    for (int i = tid; i < ni; i += BLOCK) {
+        const double x = c.xg[i];
+        C.xg[i] = (T)x;
+        if constexpr (!std::is_same<T, double>::value) C.xgd[i] = x;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void stage_rho(const StageCarve<T> &C, const ColPtrs c, int nc, int tid, bool rho)
+{
+    for (int i = tid; i < nc; i += BLOCK) {
+        C.gs[i] = (T)c.grids[i];
+        if (rho) C.rho2[i] = Real<T>::pair((T)c.rhobar[i], (i < nc - 1) ? (T)c.slrho[i] : T(0));
+    }
+}
+// packed shear table from the float64 shear columns in LDS (fused column update)
+template <typename T>
+__device__ __forceinline__ void pack_shear_table(typename Real<T>::quad_t *sh, const double *du, const double *dv,
+                                                 const double *xgd, int ni, int tid)
+{
+    for (int i = tid; i < ni; i += BLOCK) {
+        const bool in = i < ni - 1;
+        sh[i] = Real<T>::quad((T)du[i], in ? (T)column_slope(du, xgd, i) : T(0),
+                              (T)dv[i], in ? (T)column_slope(dv, xgd, i) : T(0));
+    }
 }
 
 // (A register double-buffered "prefetch next tile" variant was measured and dropped: its ~50
 // extra VGPRs cost a wave of occupancy, capping it at 128 VGPRs spilled, and every spill reload
 // carries s_waitcnt vmcnt(0), which drains the prefetch.  The other resident workgroups cover
 // a workgroup's load latency instead.)
-template <int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH = 2, bool GROUPRED = false,
+template <typename T, int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH = 2, bool GROUPRED = false,
           bool LAG = false, bool RELAUNCH = false>
-__global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
+__global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgsT<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
     constexpr bool NEED_RHO = SAT || (DIRECT && STAGE == 2);
-    // LDS: [sh: ni x {dudz, slu, dvdz, slv}] [rho2: nc x {rhobar, slope}] [xg: ni] [gs: nc] [rows] [rng]
-    double4 *s_sh = reinterpret_cast<double4 *>(lds);
-    double2 *s_rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);          // (NEED_RHO)
-    double *s_xg = lds + 4 * ni + 2 * nc;
-    double *s_gs = s_xg + ni;                                // [nc]   (DEPOSIT or NEED_RHO)
-    double *s_rows = s_gs + nc;                              // [WAVES][2][ncp] (DEPOSIT)
-    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * 2 * ncp);
-    // prologue scratch aliases the per-wave rows (zeroed afterwards): F [2][ng], u, v [nc], du, dv [ni]
-    double *s_F = s_rows, *s_u = s_F + 2 * ng, *s_v = s_u + nc, *s_du = s_v + nc, *s_dv = s_du + ni;
+    const StageCarve<T> C(lds, ng);
+    double *s_rows = C.rows;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long start = (long long)blockIdx.x * a.rays_per_block;
@@ -705,83 +807,69 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgs a)
         c_qu = a.cin.q_uu[jc]; c_qv = a.cin.q_vv[jc];
         c_rho = a.c.rhobar[jc]; c_pg0 = a.pg[jc]; c_pg1 = a.pg[nc + jc];
     }
-    TileRegs cur;
-    load_tile<STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, start, tid, end);
+    TileRegs<T> cur;
+    load_tile<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT>(cur, a, start, tid, end);
 
-    for (int i = tid; i < ni; i += BLOCK) s_xg[i] = a.c.xg[i];
+    stage_xg(C, a.c, ni, tid);
     if (fuse) {
         // (1) finish the flux reduction
         if (tid < ncols) {
             const int p = tid / ncp, c = tid - p * ncp;
-            s_F[p * ng + 1 + c] = c_tot;                     // pm_flux[:, 1:-1]  (:654)
+            C.F[p * ng + 1 + c] = c_tot;                     // pm_flux[:, 1:-1]  (:654)
         }
         __syncthreads();
-        column_flux_ends(tid, ng, s_F);
+        column_flux_ends(tid, ng, C.F);
         __syncthreads();
         // (2) RK stage of uu, vv (:665-666, :693-698); workgroup 0 publishes the new column
         if (tid < nc) {
             double du, dv, un, vn, qu, qv;
-            column_tendency(tid, ng, a.f0, a.dzg, 0, s_F, c_rho, c_pg0, c_pg1, c_u, c_v, du, dv);
-            column_rk(a.col_stage, a.dt, du, dv, c_u, c_v, c_qu, c_qv, un, vn, qu, qv);
-            s_u[tid] = un; s_v[tid] = vn;
+            column_tendency(tid, ng, a.f0, a.dzg, 0, C.F, c_rho, c_pg0, c_pg1, c_u, c_v, du, dv);
+            column_rk(a.col_stage, a.dtc, du, dv, c_u, c_v, c_qu, c_qv, un, vn, qu, qv);
+            C.u[tid] = un; C.v[tid] = vn;
             if (blockIdx.x == 0) { a.cout.uu[tid] = un; a.cout.vv[tid] = vn; a.cout.q_uu[tid] = qu; a.cout.q_vv[tid] = qv; }
         }
         __syncthreads();
         // (3) shear + np.interp slopes straight into the packed LDS table
-        column_shear(tid, BLOCK, ng, a.dzg, s_u, s_v, s_du, s_dv);
+        column_shear(tid, BLOCK, ng, a.dzg, C.u, C.v, C.du, C.dv);
         __syncthreads();
-        for (int i = tid; i < ni; i += BLOCK) {
-            const bool in = i < ni - 1;
-            s_sh[i] = make_double4(s_du[i], in ? column_slope(s_du, s_xg, i) : 0.0,
-                                   s_dv[i], in ? column_slope(s_dv, s_xg, i) : 0.0);
-        }
+        pack_shear_table<T>(C.sh, C.du, C.dv, C.xgd, ni, tid);
         __syncthreads();                                     // scratch is re-used as the wave rows below
     } else {
-        for (int i = tid; i < ni; i += BLOCK) {
-            const bool in = i < ni - 1;                      // the last point has no slope (never used)
-            s_sh[i] = make_double4(a.c.dudz[i], in ? a.c.slu[i] : 0.0, a.c.dvdz[i], in ? a.c.slv[i] : 0.0);
-        }
+        stage_shear_table(C, a.c, ni, tid);
     }
-    if (DEPOSIT || NEED_RHO)
-        for (int i = tid; i < nc; i += BLOCK) s_gs[i] = a.c.grids[i];
-    if (NEED_RHO)
-        for (int i = tid; i < nc; i += BLOCK)
-            s_rho2[i] = make_double2(a.c.rhobar[i], (i < nc - 1) ? a.c.slrho[i] : 0.0);
+    if (DEPOSIT || NEED_RHO) stage_rho(C, a.c, nc, tid, NEED_RHO);
     if (DEPOSIT)
         for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) s_rows[i] = 0.0;
     __syncthreads();
     MSGW_STAMP_AT(1);
 
     int wmin = INT_MAX, wmax = INT_MIN;
-    const StageLds L{s_sh, s_rho2, s_xg, s_gs, s_rows};
-    process_tiles<STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH, LAG, 0, RELAUNCH>(a, L, cur, start, end, tid, wave, lane, wmin, wmax);
+    const StageLds<T> L{C.sh, C.rho2, C.xg, C.gs, s_rows};
+    process_tiles<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH, LAG, 0, RELAUNCH>(a, L, cur, start, end, tid, wave, lane, wmin, wmax);
     if (DEPOSIT) {
-        if (GROUPRED) flush_rows_group<2>(s_rows, ncp, s_rng, lds /* interp tables are dead by now */, tid, a);
-        else flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
+        if (GROUPRED) flush_rows_group<2, T>(s_rows, ncp, C.rng, lds /* interp tables are dead by now */, tid, a);
+        else flush_rows<2>(s_rows, ncp, C.rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
     }
     MSGW_STAMP_AT(6);
 }
 
 // Deposit-only launch that seeds the lagged launch chain: F_0 = wave_projection(state_0) into the
 // group rows (same LDS carve and group reduction as k_ray_stage).
-template <bool FVEC>
-__global__ void __launch_bounds__(BLOCK) k_deposit_only(const StageArgs a)
+template <typename T, bool FVEC>
+__global__ void __launch_bounds__(BLOCK) k_deposit_only(const StageArgsT<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
-    double *s_xg = lds + 4 * ni + 2 * nc;
-    double *s_gs = s_xg + ni;
-    double *s_rows = s_gs + nc;
-    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * 2 * ncp);
+    const int ng = a.ng, nc = ng - 1, ncp = ng - 2;
+    const StageCarve<T> C(lds, ng);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long start = (long long)blockIdx.x * a.rays_per_block;
     const long long end = min(a.n, start + a.rays_per_block);
-    for (int i = tid; i < nc; i += BLOCK) s_gs[i] = a.c.grids[i];
-    for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) s_rows[i] = 0.0;
+    stage_rho(C, a.c, nc, tid, false);
+    for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) C.rows[i] = 0.0;
     __syncthreads();
-    const StageLds L{nullptr, nullptr, s_xg, s_gs, s_rows};
-    deposit_pass<FVEC, 2>(a, L, start, end, tid, wave, lane);
-    flush_rows_group<2>(s_rows, ncp, s_rng, lds, tid, a);
+    const StageLds<T> L{nullptr, nullptr, C.xg, C.gs, C.rows};
+    deposit_pass<T, FVEC, 2>(a, L, start, end, tid, wave, lane);
+    flush_rows_group<2, T>(C.rows, ncp, C.rng, lds, tid, a);
 }
 
 // ------------------------------------------------------------------ K1f: fixed background, whole RK3 step in registers
@@ -789,27 +877,24 @@ __global__ void __launch_bounds__(BLOCK) k_deposit_only(const StageArgs a)
 // dependency, so the three stages run back to back per ray, and ALL the steps of
 // a call run in one launch: rr, mm (dens) touch HBM once per call, not per step
 // (same arithmetic in the same order: bit-identical to one launch per step).
-template <bool SAT, bool FVEC, bool DIRECT>
-__global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
+template <typename T, bool SAT, bool FVEC, bool DIRECT>
+__global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgsT<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int RPT = Real<T>::RPT;
+    constexpr int TILE = Real<T>::TILE;
+    typedef typename Real<T>::quad_t quad_t;
+    typedef typename Real<T>::pair_t pair_t;
     const int ng = a.ng, ni = ng - 2, nc = ng - 1;
     constexpr bool NEED_RHO = SAT || DIRECT;
-    double4 *s_sh = reinterpret_cast<double4 *>(lds);
-    double2 *s_rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);
-    double *s_xg = lds + 4 * ni + 2 * nc;
-    double *s_gs = s_xg + ni;
+    const StageCarve<T> C(lds, ng);
+    const quad_t *s_sh = C.sh;
+    const pair_t *s_rho2 = C.rho2;
+    const T *s_xg = C.xg, *s_gs = C.gs;
     const int tid = threadIdx.x;
-    for (int i = tid; i < ni; i += BLOCK) {
-        s_xg[i] = a.c.xg[i];
-        const bool in = i < ni - 1;
-        s_sh[i] = make_double4(a.c.dudz[i], in ? a.c.slu[i] : 0.0, a.c.dvdz[i], in ? a.c.slv[i] : 0.0);
-    }
-    if (NEED_RHO)
-        for (int i = tid; i < nc; i += BLOCK) {
-            s_gs[i] = a.c.grids[i];
-            s_rho2[i] = make_double2(a.c.rhobar[i], (i < nc - 1) ? a.c.slrho[i] : 0.0);
-        }
+    stage_xg(C, a.c, ni, tid);
+    stage_shear_table(C, a.c, ni, tid);
+    if (NEED_RHO) stage_rho(C, a.c, nc, tid, true);
     __syncthreads();
 
     const long long start = (long long)blockIdx.x * a.rays_per_block;
@@ -817,122 +902,129 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgs a)
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = start + (long long)t * TILE;
         if (base >= end) break;
-        const long long e0 = base + 2 * tid;
-        const unsigned int i0 = (unsigned int)(e0 * 8);
+        const long long e0 = base + RPT * tid;
+        const unsigned int i0 = (unsigned int)(e0 * (long long)sizeof(T));
         const bool own = e0 < end;
-        double rr[2], mm[2], kk[2], ll[2], dens[2], ff[2], pvf[2];
-        load2(a.r.rr, i0, rr);
-        load2(a.r.mm, i0, mm);
-        load2(a.r.kk, i0, kk);
-        load2(a.r.ll, i0, ll);
-        if (FVEC) load2(a.r.fray, i0, ff);
-        if (NEED_RHO) { load2(a.r.dens, i0, dens); load2(a.r.pvf, i0, pvf); }
-        double sd[2] = {0.0, 0.0}, sr[2] = {0.0, 0.0}, sm[2] = {0.0, 0.0}, drr[2] = {0.0, 0.0};
+        T rr[RPT], mm[RPT], kk[RPT], ll[RPT], dens[RPT], ff[RPT], pvf[RPT];
+        loadv(a.r.rr, i0, rr);
+        loadv(a.r.mm, i0, mm);
+        loadv(a.r.kk, i0, kk);
+        loadv(a.r.ll, i0, ll);
+        if (FVEC) loadv(a.r.fray, i0, ff);
+        if (NEED_RHO) { loadv(a.r.dens, i0, dens); loadv(a.r.pvf, i0, pvf); }
+        T sd[RPT], sr[RPT], sm[RPT], drr[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) { sd[r] = T(0); sr[r] = T(0); sm[r] = T(0); drr[r] = T(0); }
         if (a.relaunch) {                                     // workgroup-uniform
-            load2(a.r.src_dens, i0, sd); load2(a.r.src_rr, i0, sr); load2(a.r.src_mm, i0, sm);
-            load2(a.r.drr, i0, drr);
-            if (!NEED_RHO) load2(a.r.dens, i0, dens);
+            loadv(a.r.src_dens, i0, sd); loadv(a.r.src_rr, i0, sr); loadv(a.r.src_mm, i0, sm);
+            loadv(a.r.drr, i0, drr);
+            if (!NEED_RHO) loadv(a.r.dens, i0, dens);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const double f = FVEC ? ff[r] : a.f_uni;
-            const double f2 = f * f;
-            const double kh2 = kk[r] * kk[r] + ll[r] * ll[r];
+        for (int r = 0; r < RPT; ++r) {
+            const T f = FVEC ? ff[r] : a.f_uni;
+            const T f2 = f * f;
+            const T kh2 = kk[r] * kk[r] + ll[r] * ll[r];
           for (int step = 0; step < a.fixed_steps; ++step) {
-            const double rr_old = rr[r], mm_old = mm[r];
-            double q_r = 0.0, q_m = 0.0, q_d = 0.0;
+            const T rr_old = rr[r], mm_old = mm[r];
+            T q_r = T(0), q_m = T(0), q_d = T(0);
 #pragma unroll
             for (int st = 0; st < 3; ++st) {
-                const double m2 = mm[r] * mm[r];
-                const double vk2 = kh2 + m2;
-                const double om = sqrt((a.bvf2 * kh2 + f2 * m2) / vk2);
-                const double cgr = -mm[r] * (om * om - f2) / om / vk2;
-                const double st_rr = .5 * (cgr + cgr);
-                const Bracket bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
-                const double4 sh = s_sh[bk.j];
-                const double gu = interp_eval(rr[r], bk, sh.x, sh.y);
-                const double gv = interp_eval(rr[r], bk, sh.z, sh.w);
-                const double st_mm = (kk[r] * 0.0 + ll[r] * 0.0) - (kk[r] * gu + ll[r] * gv);
-                double st_dens = 0.0;
+                const T m2 = mm[r] * mm[r];
+                const T vk2 = kh2 + m2;
+                const T om = sqrt((a.bvf2 * kh2 + f2 * m2) / vk2);
+                const T cgr = -mm[r] * (om * om - f2) / om / vk2;
+                const T st_rr = T(.5) * (cgr + cgr);
+                const Bracket<T> bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
+                const quad_t sh = s_sh[bk.j];
+                const T gu = interp_eval(rr[r], bk, sh.x, sh.y);
+                const T gv = interp_eval(rr[r], bk, sh.z, sh.w);
+                const T st_mm = (kk[r] * T(0) + ll[r] * T(0)) - (kk[r] * gu + ll[r] * gv);
+                T st_dens = T(0);
                 if (SAT) {
-                    const double rr_f = rr[r] + st_rr * a.dt;
-                    const double mm_f = mm[r] + st_mm * a.dt;
-                    const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
-                    const double2 rh = s_rho2[br.j];                                   // {rhobar, slope}
-                    const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);   // :595
-                    const double omh = a.same_f ? om : sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);
-                    const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
+                    const T rr_f = rr[r] + st_rr * a.dt;
+                    const T mm_f = mm[r] + st_mm * a.dt;
+                    const Bracket<T> br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+                    const pair_t rh = s_rho2[br.j];                                    // {rhobar, slope}
+                    const T rho_f = interp_eval(rr_f, br, rh.x, rh.y);        // :595
+                    const T omh = a.same_f ? om : sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);
+                    const T maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
                     if (maxd < dens[r] * pvf[r]) st_dens = (maxd - dens[r]) / a.dt;
                 }
                 if (st == 0) {
                     q_r = a.dt * st_rr; q_m = a.dt * st_mm;
-                    rr[r] = rr[r] + div_const(q_r, 3.0, THIRD_RN, 1);
-                    mm[r] = mm[r] + div_const(q_m, 3.0, THIRD_RN, 1);
-                    if (SAT) { q_d = a.dt * st_dens; dens[r] = dens[r] + div_const(q_d, 3.0, THIRD_RN, 1); }
+                    rr[r] = rr[r] + div_const(q_r, T(3), third_rn<T>(), 1);
+                    mm[r] = mm[r] + div_const(q_m, T(3), third_rn<T>(), 1);
+                    if (SAT) { q_d = a.dt * st_dens; dens[r] = dens[r] + div_const(q_d, T(3), third_rn<T>(), 1); }
                 } else {
-                    const double A = (st == 1) ? RK_A1 : RK_A2, B = (st == 1) ? RK_B1 : RK_B2;
+                    const T A = (st == 1) ? T(RK_A1) : T(RK_A2), B = (st == 1) ? T(RK_B1) : T(RK_B2);
                     q_r = a.dt * st_rr - A * q_r; q_m = a.dt * st_mm - A * q_m;
                     rr[r] = rr[r] + B * q_r; mm[r] = mm[r] + B * q_m;
                     if (SAT) { q_d = a.dt * st_dens - A * q_d; dens[r] = dens[r] + B * q_d; }
                 }
             }
             if (DIRECT) {
-                const double rr_st = (rr[r] - rr_old) / a.sat_rr_div;
-                const double mm_st = (mm[r] - mm_old) / a.dt;
-                const double rr_f = rr_old + rr_st * a.dt;
-                const double mm_f = mm_old + mm_st * a.dt;
-                const Bracket br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
-                const double2 rh = s_rho2[br.j];                                   // {rhobar, slope}
-                const double rho_f = interp_eval(rr_f, br, rh.x, rh.y);   // :595
-                const double m02 = mm_old * mm_old;
-                const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m02) / (kh2 + m02));
-                const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
+                const T rr_st = (rr[r] - rr_old) / a.sat_rr_div;
+                const T mm_st = (mm[r] - mm_old) / a.dt;
+                const T rr_f = rr_old + rr_st * a.dt;
+                const T mm_f = mm_old + mm_st * a.dt;
+                const Bracket<T> br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
+                const pair_t rh = s_rho2[br.j];                                    // {rhobar, slope}
+                const T rho_f = interp_eval(rr_f, br, rh.x, rh.y);        // :595
+                const T m02 = mm_old * mm_old;
+                const T omh = sqrt((a.bvf2 * kh2 + a.f0sq * m02) / (kh2 + m02));
+                const T maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
                 if (maxd < dens[r] * pvf[r]) dens[r] = maxd;
             }
             if (a.relaunch) {                                 // EXTENSION MSGW_RELAUNCH (include/msgwam_hip.h)
-                const bool out = (rr[r] - .5 * drr[r] > a.z_top) || (rr[r] + .5 * drr[r] < a.z_bot) ||
+                const bool out = (rr[r] - T(.5) * drr[r] > a.z_top) || (rr[r] + T(.5) * drr[r] < a.z_bot) ||
                                  (dens[r] < a.relaunch_frac * sd[r]);
                 if (out) { dens[r] = sd[r]; rr[r] = sr[r]; mm[r] = sm[r]; }
             }
           }
         }
         if (own) {
-            store2(a.r.rr, i0, rr);
-            store2(a.r.mm, i0, mm);
-            if (NEED_RHO || a.relaunch) store2(a.r.dens, i0, dens);
+            storev(a.r.rr, i0, rr);
+            storev(a.r.mm, i0, mm);
+            if (NEED_RHO || a.relaunch) storev(a.r.dens, i0, dens);
         }
     }
 }
 
 // ------------------------------------------------------------------ diagnostics: wave_projection(var) on any grid
-struct ProjExplicit {     // caller-supplied arrays of lprop.wave_projection (:92-94)
+struct ProjExplicit {     // caller-supplied arrays of lprop.wave_projection (:92-94), always float64
     const double *dens, *lo, *up, *kk, *ll, *mlo, *mup, *dkk, *dll, *dmm, *fray;
 };
-struct ProjArgs {
+template <typename T>
+struct ProjArgsT {
     long long n;
     int nG;               // points of G; output has nG-1 levels
     int tiles_per_block;
     int var;              // payload: 0 pseudo-momentum fluxes (NP = 2), 1 wave-action flux, 2 wave action
     int boundary;         // 1: var 3 / 4 (:199-219) -- sums at the interfaces nb with nlow < nb < nup, unit weight
-    double bvf2, f_uni, dz, cdz;
+    T bvf2, f_uni, dz, cdz;
     int mk_ok;
-    RayPtrs r;            // resident rays   (EXPL = false)
-    ProjExplicit e;       // explicit arrays (EXPL = true)
+    RayPtrsT<T> r;        // resident rays   (EXPL = false)
+    ProjExplicit e;       // explicit arrays (EXPL = true; T = double)
     const double *G;
     double *partial;      // [blocks][NP][nG-1]
     int *ranges;
 };
+typedef ProjArgsT<double> ProjArgs;
 
-template <int NP, bool FVEC, bool EXPL>
-__global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
+template <typename T, int NP, bool FVEC, bool EXPL>
+__global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
 {
+    static_assert(!EXPL || std::is_same<T, double>::value, "caller arrays are float64");
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int RPT = Real<T>::RPT;
+    constexpr int TILE = Real<T>::TILE;
     const int nG = a.nG, ncp = nG - 1;
-    double *s_G = lds;
-    double *s_rows = s_G + nG;
-    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * NP * ncp);
+    double *s_rows = lds;                                    // [WAVES][NP][ncp] float64
+    int *s_rng = reinterpret_cast<int *>(s_rows + WAVES * NP * ncp);   // [2*WAVES]
+    T *s_G = reinterpret_cast<T *>(s_rng + 2 * WAVES);       // [nG]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < nG; i += BLOCK) s_G[i] = a.G[i];
+    for (int i = tid; i < nG; i += BLOCK) s_G[i] = (T)a.G[i];
     for (int i = tid; i < WAVES * NP * ncp; i += BLOCK) s_rows[i] = 0.0;
     __syncthreads();
     int wmin = INT_MAX, wmax = INT_MIN;
@@ -941,64 +1033,65 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgs a)
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = (tile0 + t) * (long long)TILE;
         if (base >= a.n) break;
-        const long long e0 = base + 2 * tid;
-        const unsigned int i0 = (unsigned int)(e0 * 8);
-        const bool v0 = e0 < a.n, v1 = e0 + 1 < a.n;
-        const bool valid[2] = {v0, v1};
-        double kk[2], ll[2], dens[2], vol[2], ff[2], lo[2], up[2], mmid[2];
-        if (EXPL) {
-            double mlo[2], mup[2], dkk[2], dll[2], dmm[2];
-            load2(a.e.dens, i0, dens);
-            load2(a.e.lo, i0, lo);
-            load2(a.e.up, i0, up);
-            load2(a.e.kk, i0, kk);
-            load2(a.e.ll, i0, ll);
-            load2(a.e.mlo, i0, mlo);
-            load2(a.e.mup, i0, mup);
-            load2(a.e.dkk, i0, dkk);
-            load2(a.e.dll, i0, dll);
-            load2(a.e.dmm, i0, dmm);
-            load2(a.e.fray, i0, ff);
+        const long long e0 = base + RPT * tid;
+        const unsigned int i0 = (unsigned int)(e0 * (long long)sizeof(T));
+        bool valid[RPT];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RPT; ++r) valid[r] = e0 + r < a.n;
+        T kk[RPT], ll[RPT], dens[RPT], vol[RPT], ff[RPT], lo[RPT], up[RPT], mmid[RPT];
+        if constexpr (EXPL) {
+            T mlo[RPT], mup[RPT], dkk[RPT], dll[RPT], dmm[RPT];
+            loadv(a.e.dens, i0, dens);
+            loadv(a.e.lo, i0, lo);
+            loadv(a.e.up, i0, up);
+            loadv(a.e.kk, i0, kk);
+            loadv(a.e.ll, i0, ll);
+            loadv(a.e.mlo, i0, mlo);
+            loadv(a.e.mup, i0, mup);
+            loadv(a.e.dkk, i0, dkk);
+            loadv(a.e.dll, i0, dll);
+            loadv(a.e.dmm, i0, dmm);
+            loadv(a.e.fray, i0, ff);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
                 vol[r] = fabs(dkk[r] * dll[r] * dmm[r]);              // :137
-                mmid[r] = .5 * (mlo[r] + mup[r]);                     // :141
+                mmid[r] = T(.5) * (mlo[r] + mup[r]);                  // :141
             }
         } else {
-            double rr[2], mm[2], drr[2], dmm[2];
-            load2(a.r.rr, i0, rr);
-            load2(a.r.mm, i0, mm);
-            load2(a.r.kk, i0, kk);
-            load2(a.r.ll, i0, ll);
-            load2(a.r.dens, i0, dens);
-            load2(a.r.drr, i0, drr);
-            load2(a.r.dmm, i0, dmm);
-            load2(a.r.vol, i0, vol);
-            if (FVEC) load2(a.r.fray, i0, ff);
+            T rr[RPT], mm[RPT], drr[RPT], dmm[RPT];
+            loadv(a.r.rr, i0, rr);
+            loadv(a.r.mm, i0, mm);
+            loadv(a.r.kk, i0, kk);
+            loadv(a.r.ll, i0, ll);
+            loadv(a.r.dens, i0, dens);
+            loadv(a.r.drr, i0, drr);
+            loadv(a.r.dmm, i0, dmm);
+            loadv(a.r.vol, i0, vol);
+            if (FVEC) loadv(a.r.fray, i0, ff);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                lo[r] = rr[r] - .5 * drr[r];                          // :655 / raytracer.py:200-201
-                up[r] = rr[r] + .5 * drr[r];
-                mmid[r] = .5 * ((mm[r] - .5 * dmm[r]) + (mm[r] + .5 * dmm[r]));   // :141, :656
+            for (int r = 0; r < RPT; ++r) {
+                lo[r] = rr[r] - T(.5) * drr[r];                       // :655 / raytracer.py:200-201
+                up[r] = rr[r] + T(.5) * drr[r];
+                mmid[r] = T(.5) * ((mm[r] - T(.5) * dmm[r]) + (mm[r] + T(.5) * dmm[r]));   // :141, :656
             }
         }
-        double pay[NP][2];
-        int nlo[2], nup[2];
+        T pay[NP][RPT];
+        int nlo[RPT], nup[RPT];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             deposit_indices<NP>(lo[r], up[r], valid[r], a.dz, a.cdz, a.mk_ok, nG - 2, nlo[r], nup[r]);
             if (a.boundary) {            // interfaces nlow+1 .. nup-1 (:205, :216); weight |G[nb+1]-G[nb]|/dz = 1
                 nlo[r] += 1;
-                lo[r] = -1e300; up[r] = 1e300;
+                lo[r] = T(-1e30); up[r] = T(1e30);
             }
-            const double f = (FVEC || EXPL) ? ff[r] : a.f_uni;
-            double kh2, m2, vk2, om, cgr;
+            const T f = (FVEC || EXPL) ? ff[r] : a.f_uni;
+            T kh2, m2, vk2, om, cgr;
             dispersion(kk[r], ll[r], mmid[r], f * f, a.bvf2, kh2, m2, vk2, om, cgr);
             if (NP == 2) { pay[0][r] = cgr * kk[r] * dens[r]; pay[NP - 1][r] = cgr * ll[r] * dens[r]; }   // :148-149
             else pay[0][r] = (a.var == 1) ? cgr * dens[r] : dens[r];                     // :167, :184
         }
-        deposit_tile<NP, 0>(lo, up, nlo, nup, vol, pay, s_G, a.dz, a.cdz, a.mk_ok,
-                            s_rows + wave * NP * ncp, ncp, lane, wmin, wmax, acc0);
+        deposit_tile<NP, 0, T>(lo, up, nlo, nup, vol, pay, s_G, a.dz, a.cdz, a.mk_ok,
+                               s_rows + wave * NP * ncp, ncp, lane, wmin, wmax, acc0);
     }
     flush_rows<NP>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
 }
@@ -1012,45 +1105,35 @@ struct SatArgs {
     const double *grids, *rhobar, *slrho;
     double *out;
 };
-__global__ void __launch_bounds__(BLOCK) k_saturation(const SatArgs a)
-{
-    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= a.n) return;
-    const double rr_f = a.rr[i] + a.rr_st[i] * a.dt;                 // :591
-    const double drr_f = a.drr[i] + a.drr_st[i] * a.dt;              // :592
-    const double mm_f = a.mm[i] + a.mm_st[i] * a.dt;                 // :593
-    const double dmm_f = a.area[i] / drr_f;                          // :594
-    const Bracket br = interp_locate(rr_f, a.grids, a.nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
-    const double rho_f = interp_eval(rr_f, br, a.rhobar[br.j], a.slrho[min(br.j, a.nc - 2)]);   // :595
-    const double kh2 = a.kk[i] * a.kk[i] + a.ll[i] * a.ll[i];
-    const double m2 = a.mm[i] * a.mm[i];
-    const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m2) / (kh2 + m2));          // :597
-    const double pv = a.dkk[i] * a.dll[i] * dmm_f;                   // :599
-    const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);      // :601
-    const double d = a.dens[i];
-    const bool hit = maxd < d * pv;                                  // :604
-    if (a.direct) a.out[i] = hit ? maxd : d;                         // :606-610
-    else a.out[i] = hit ? (maxd - d) / a.dt : 0.0;                   // :612-615
-}
 
-// ------------------------------------------------------------------ upload helpers
+// ------------------------------------------------------------------ upload / download helpers
 // inert padding rays [from, to) so that whole-tile vector accesses stay in initialised memory
-__global__ void k_fill_range(double *p, long long from, long long to, double v)
+template <typename T>
+__global__ void k_fill_range(T *p, long long from, long long to, T v)
 {
     const long long i = from + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < to) p[i] = v;
 }
 
 // vol = |dkk*dll*dmm| (:137) and pvf = dkk*dll*(rr_mm_area/drr) (:594, :599 with
-// drr_final = drr + 0*dt) once per upload.
+// drr_final = drr + 0*dt) once per upload, from the caller's float64 values.
+template <typename T>
 __global__ void k_prepare(long long n, const double *dkk, const double *dll, const double *area,
-                          const double *drr, const double *dmm, double *vol, double *pvf)
+                          const double *drr, const double *dmm, T *vol, T *pvf)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double dkdl = dkk[i] * dll[i];
-    vol[i] = fabs(dkdl * dmm[i]);
-    pvf[i] = dkdl * (area[i] / drr[i]);
+    vol[i] = (T)fabs(dkdl * dmm[i]);
+    pvf[i] = (T)(dkdl * (area[i] / drr[i]));
+}
+
+// float32 state: the C ABI speaks float64 (the reference's arrays); convert on the device
+template <typename A, typename B>
+__global__ void k_convert(long long n, const A *src, B *dst)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (B)src[i];
 }
 
 }   // namespace msgw

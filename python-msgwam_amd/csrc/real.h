@@ -1,0 +1,62 @@
+// Scalar type of the per-ray state: float64 (the reference's, bit-comparable with numpy) or float32
+// (BASELINE config 5: throughput mode, half the bytes per ray).  Everything per ray is templated on
+// `T`; the flux rows, their reduction over workgroups / ranks and the mean-flow column are float64
+// in both modes.  A lane always moves 16 bytes per array access: 2 rays of float64 or
+// 4 rays of float32, so a 256-thread workgroup advances a tile of 512 / 1024 rays.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits>
+#include <type_traits>
+
+namespace msgw {
+
+constexpr int BLOCK = 256;           // 4 wavefronts
+constexpr int WAVES = BLOCK / 64;
+
+template <typename T> struct Real;
+template <> struct Real<double> {
+    static constexpr int RPT = 2;                 // rays per lane -> 16-B global accesses
+    static constexpr int TILE = BLOCK * RPT;      // rays per workgroup iteration
+    typedef double2 pair_t;
+    typedef double4 quad_t;
+    static __device__ __forceinline__ pair_t pair(double x, double y) { return make_double2(x, y); }
+    static __device__ __forceinline__ quad_t quad(double x, double y, double z, double w) { return make_double4(x, y, z, w); }
+};
+template <> struct Real<float> {
+    static constexpr int RPT = 4;
+    static constexpr int TILE = BLOCK * RPT;
+    typedef float2 pair_t;
+    typedef float4 quad_t;
+    static __device__ __forceinline__ pair_t pair(float x, float y) { return make_float2(x, y); }
+    static __device__ __forceinline__ quad_t quad(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+};
+
+// Every per-ray array is allocated and initialised up to a whole number of tiles (the host pads
+// with inert rays), so all accesses are UNCONDITIONAL 16-B vector accesses: a conditional
+// load makes hipcc branch around it and wait vmcnt(0) per load, which serialises the nine
+// streams of a tile into nine memory round trips (measured: 27 us vs 16 us per launch).
+// Addressing: uniform base pointer (SGPR pair) + ONE 32-bit byte offset shared by all SoA
+// arrays of a tile (global_load ... v_off, s[base] form) instead of a 64-bit VGPR address
+// per array: saves ~26 VGPRs and the address arithmetic.  Limits a context to 2^29 rays.
+__device__ __forceinline__ void loadv(const double *p, unsigned int off, double (&out)[2])
+{
+    const double2 t = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(p) + off);   // 16 B per lane
+    out[0] = t.x; out[1] = t.y;
+}
+__device__ __forceinline__ void storev(double *p, unsigned int off, const double (&v)[2])
+{
+    *reinterpret_cast<double2 *>(reinterpret_cast<char *>(p) + off) = make_double2(v[0], v[1]);
+}
+__device__ __forceinline__ void loadv(const float *p, unsigned int off, float (&out)[4])
+{
+    const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(p) + off);
+    out[0] = t.x; out[1] = t.y; out[2] = t.z; out[3] = t.w;
+}
+__device__ __forceinline__ void storev(float *p, unsigned int off, const float (&v)[4])
+{
+    *reinterpret_cast<float4 *>(reinterpret_cast<char *>(p) + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <typename T> __device__ __forceinline__ T real_inf() { return std::numeric_limits<T>::infinity(); }
+
+}   // namespace msgw

@@ -21,9 +21,11 @@ DIRECT_SAT = 4
 NO_GRAPH = 8
 TIME_KERNELS = 16
 RELAUNCH = 32           # extension, see include/msgwam_hip.h
+DTYPE_F32 = 1           # msgw_create_ex flag: float32 ray state (BASELINE config 5)
+TRANSPORTS = {0: "none", 1: "rccl", 2: "host_shm", 3: "device_ipc"}
 
 EXPORTS = [
-    "msgw_abi_version", "msgw_last_error", "msgw_create", "msgw_destroy", "msgw_set_config",
+    "msgw_abi_version", "msgw_last_error", "msgw_create", "msgw_create_ex", "msgw_destroy", "msgw_set_config",
     "msgw_set_column", "msgw_upload_rays", "msgw_step", "msgw_rhs", "msgw_project",
     "msgw_project_arrays", "msgw_saturation", "msgw_download_rays", "msgw_download_column",
     "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters", "msgw_set_relaunch", "msgw_upload_hprop", "msgw_download_hprop",
@@ -38,7 +40,8 @@ class Counters(C.Structure):
                 ("nray", C.c_int64), ("ngrid", C.c_int32), ("blocks", C.c_int32),
                 ("graph_steps", C.c_int32), ("nranks", C.c_int32), ("persist_steps", C.c_int32),
                 ("exchange", C.c_int32),
-                ("persist_resident_tiles", C.c_int32), ("reserved_", C.c_int32)]
+                ("persist_resident_tiles", C.c_int32), ("elem_bytes", C.c_int32),
+                ("transport", C.c_int32), ("tenants", C.c_int32)]
 
 
 class MsgwError(RuntimeError):
@@ -60,6 +63,7 @@ def load_library():
     lib.msgw_last_error.restype = C.c_char_p
     lib.msgw_last_error.argtypes = [C.c_void_p]
     lib.msgw_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int]
+    lib.msgw_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_uint]
     lib.msgw_destroy.argtypes = [C.c_void_p]
     lib.msgw_set_config.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
     lib.msgw_set_column.argtypes = [C.c_void_p] + [_dp] * 6
@@ -79,7 +83,7 @@ def load_library():
     lib.msgw_set_relaunch.argtypes = [C.c_void_p, C.c_double]
     lib.msgw_upload_hprop.argtypes = [C.c_void_p, C.c_int64, _dp, _dp]
     lib.msgw_download_hprop.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp, _dp, _dp, _dp]
-    if lib.msgw_abi_version() != 1:
+    if lib.msgw_abi_version() != 2:
         raise MsgwError("libmsgwam_hip.so has an unexpected ABI version")
     _lib = lib
     return lib
@@ -110,13 +114,17 @@ def comm_unique_id():
 class Propagator:
     """One GPU context: the ray state and the column live in HBM between calls."""
 
-    def __init__(self, ngrid, nray_cap, device=0):
+    def __init__(self, ngrid, nray_cap, device=0, dtype="f64"):
+        """dtype "f64" (default; the reference's precision) or "f32" (BASELINE config 5: float32 ray state)."""
+        if dtype not in ("f64", "f32"):
+            raise ValueError("dtype must be 'f64' or 'f32'")
         self.lib = load_library()
         self.ctx = C.c_void_p()
-        self.ngrid, self.cap, self.n = int(ngrid), int(nray_cap), 0
-        rc = self.lib.msgw_create(C.byref(self.ctx), int(device), self.cap, self.ngrid)
+        self.ngrid, self.cap, self.n, self.dtype = int(ngrid), int(nray_cap), 0, dtype
+        rc = self.lib.msgw_create_ex(C.byref(self.ctx), int(device), self.cap, self.ngrid,
+                                     DTYPE_F32 if dtype == "f32" else 0)
         if rc:
-            raise MsgwError(f"msgw_create: {self.lib.msgw_last_error(None).decode()} (rc={rc})")
+            raise MsgwError(f"msgw_create_ex: {self.lib.msgw_last_error(None).decode()} (rc={rc})")
 
     def _chk(self, rc, what):
         if rc:
