@@ -62,14 +62,14 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
         double dens[2], lam[2], phi[2], rr[2], drr[2], kk[2], ll[2], mm[2], vol[2], pvf[2] = {1.0, 1.0};
         double qd[2] = {0, 0}, qla[2] = {0, 0}, qph[2] = {0, 0}, qr[2] = {0, 0}, qk[2] = {0, 0}, ql[2] = {0, 0},
                qm[2] = {0, 0};
-        loadv(a.r.dens, i0, dens); loadv(h.lam, i0, lam); loadv(h.phi, i0, phi); loadv(a.r.rr, i0, rr);
-        loadv(a.r.drr, i0, drr); loadv(h.kk, i0, kk); loadv(h.ll, i0, ll); loadv(a.r.mm, i0, mm);
-        loadv(a.r.vol, i0, vol);
-        if (SAT) loadv(a.r.pvf, i0, pvf);
+        loadv(a.r.dens(), i0, dens); loadv(h.lam, i0, lam); loadv(h.phi, i0, phi); loadv(a.r.rr(), i0, rr);
+        loadv(a.r.drr(), i0, drr); loadv(h.kk, i0, kk); loadv(h.ll, i0, ll); loadv(a.r.mm(), i0, mm);
+        loadv(a.r.vol(), i0, vol);
+        if (SAT) loadv(a.r.pvf(), i0, pvf);
         if (STAGE == 1 || STAGE == 2) {
-            loadv(h.q_lam, i0, qla); loadv(h.q_phi, i0, qph); loadv(a.r.q_rr, i0, qr); loadv(h.q_kk, i0, qk);
-            loadv(h.q_ll, i0, ql); loadv(a.r.q_mm, i0, qm);
-            if (SAT) loadv(a.r.q_dens, i0, qd);
+            loadv(h.q_lam, i0, qla); loadv(h.q_phi, i0, qph); loadv(a.r.q_rr(), i0, qr); loadv(h.q_kk, i0, qk);
+            loadv(h.q_ll, i0, ql); loadv(a.r.q_mm(), i0, qm);
+            if (SAT) loadv(a.r.q_dens(), i0, qd);
         }
         double lo[2], up[2], pay[2][2];
         double n_dens[2], n_lam[2], n_phi[2], n_rr[2], n_kk[2], n_ll[2], n_mm[2];
@@ -139,17 +139,17 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
         }
         if (valid[0]) {                                        // only the owner stores (pairs never straddle)
             if (STAGE == 3) {
-                storev(a.r.q_dens, i0, n_dens); storev(h.q_lam, i0, n_lam); storev(h.q_phi, i0, n_phi);
-                storev(a.r.q_rr, i0, n_rr); storev(h.q_kk, i0, n_kk); storev(h.q_ll, i0, n_ll);
-                storev(a.r.q_mm, i0, n_mm);
+                storev(a.r.q_dens(), i0, n_dens); storev(h.q_lam, i0, n_lam); storev(h.q_phi, i0, n_phi);
+                storev(a.r.q_rr(), i0, n_rr); storev(h.q_kk, i0, n_kk); storev(h.q_ll, i0, n_ll);
+                storev(a.r.q_mm(), i0, n_mm);
             } else {
-                if (SAT) storev(a.r.dens, i0, n_dens);
-                storev(h.lam, i0, n_lam); storev(h.phi, i0, n_phi); storev(a.r.rr, i0, n_rr);
-                storev(h.kk, i0, n_kk); storev(h.ll, i0, n_ll); storev(a.r.mm, i0, n_mm);
+                if (SAT) storev(a.r.dens(), i0, n_dens);
+                storev(h.lam, i0, n_lam); storev(h.phi, i0, n_phi); storev(a.r.rr(), i0, n_rr);
+                storev(h.kk, i0, n_kk); storev(h.ll, i0, n_ll); storev(a.r.mm(), i0, n_mm);
                 if (STAGE != 2) {
-                    if (SAT) storev(a.r.q_dens, i0, qd);
-                    storev(h.q_lam, i0, qla); storev(h.q_phi, i0, qph); storev(a.r.q_rr, i0, qr);
-                    storev(h.q_kk, i0, qk); storev(h.q_ll, i0, ql); storev(a.r.q_mm, i0, qm);
+                    if (SAT) storev(a.r.q_dens(), i0, qd);
+                    storev(h.q_lam, i0, qla); storev(h.q_phi, i0, qph); storev(a.r.q_rr(), i0, qr);
+                    storev(h.q_kk, i0, qk); storev(h.q_ll, i0, ql); storev(a.r.q_mm(), i0, qm);
                 }
             }
         }

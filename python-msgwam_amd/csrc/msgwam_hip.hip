@@ -119,7 +119,9 @@ struct msgw_ctx {
     int f32 = 0;
     size_t esz = sizeof(double);     // bytes per element of the ray arrays
     int tile = Real<double>::TILE;   // rays per workgroup iteration (16 B per lane per array)
-    std::vector<void *> ray_bufs;
+    std::vector<void *> ray_bufs;    // further per-ray allocations (the HPROP arrays)
+    char *slab = nullptr;            // ONE allocation for the A_COUNT per-ray arrays, array k at slab + k * pitch
+    size_t pitch = 0;                // bytes between two arrays (a multiple of 256)
     void *dens = nullptr, *rr = nullptr, *mm = nullptr, *drr = nullptr, *kk = nullptr, *ll = nullptr,
          *dmm = nullptr, *vol = nullptr, *fray = nullptr, *pvf = nullptr, *q_rr = nullptr,
          *q_mm = nullptr, *q_dens = nullptr, *rr0 = nullptr, *mm0 = nullptr,
@@ -416,10 +418,7 @@ int launch_list(msgw_ctx *c, const void *fn, unsigned grid, unsigned block, A...
 template <typename T>
 RayPtrsT<T> ray_ptrs(const msgw_ctx *c)
 {
-    auto p = [](void *v) { return static_cast<T *>(v); };
-    return RayPtrsT<T>{p(c->dens), p(c->rr), p(c->mm), p(c->drr), p(c->kk), p(c->ll), p(c->dmm), p(c->vol), p(c->fray),
-                       p(c->pvf), p(c->q_rr), p(c->q_mm), p(c->q_dens), p(c->rr0), p(c->mm0), p(c->src_dens),
-                       p(c->src_rr), p(c->src_mm), p(c->cgbuf)};
+    return RayPtrsT<T>{c->slab, (unsigned int)(c->pitch >> 8)};
 }
 
 // the exact constant division (div_const) needs d's significand not to be all ones
@@ -710,14 +709,8 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
 #endif
     pa.timeout_ticks = 20000000ull;                            // 0.2 s of wall clock per wait
     if (multi) {                                               // the other ranks' launches may start much later
-        XchArgs x{};
-        x.nranks = c->nranks; x.rank = c->rank; x.stride = c->xch_stride;
-        x.rows = c->xch_rows; x.flags = c->xch_flags; x.seq = c->xch_seq;
-        x.direct = c->xch_direct ? 1 : 0;
-        x.peer_rows = c->xch_peer_rows; x.peer_flags = c->xch_peer_flags;
-        x.timeout_ticks = XCH_TIMEOUT_TICKS;
-        pa.xch = x;
-        pa.has_xch = 1;
+        pa.xch = reinterpret_cast<const XchArgs *>(c->xch_scratch + 16);   // written once by xch_setup
+        pa.xch_seq = c->xch_seq;
         pa.timeout_ticks = XCH_TIMEOUT_TICKS + 100000000ull;
     }
     pa.cin = ColIn{c->uu, c->vv, c->q_uu, c->q_vv};
@@ -1099,13 +1092,16 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CR(hipEventCreate(&c->ev0));
     CR(hipEventCreate(&c->ev1));
-    void **rp[] = {&c->dens, &c->rr, &c->mm, &c->drr, &c->kk, &c->ll, &c->dmm, &c->vol, &c->fray,
-                   &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0, &c->src_dens, &c->src_rr, &c->src_mm, &c->cgbuf};
+    void **rp[A_COUNT] = {&c->dens, &c->rr, &c->mm, &c->drr, &c->kk, &c->ll, &c->dmm, &c->vol, &c->fray,
+                          &c->pvf, &c->q_rr, &c->q_mm, &c->q_dens, &c->rr0, &c->mm0, &c->src_dens, &c->src_rr, &c->src_mm,
+                          &c->cgbuf};                            // in the order of enum RayArray
     const size_t padded = (((size_t)nray_cap + c->tile - 1) / c->tile + 1) * c->tile;   // whole tiles + one: unconditional vector access
-    for (void **p : rp) {
-        CR(hipMalloc(p, padded * c->esz));
-        c->ray_bufs.push_back(*p);
-    }
+    // one slab, array k at slab + k * pitch (see RayPtrsT); the pitch gets an odd number of 256-B lines on top so
+    // that the same tile of different arrays does not start on the same memory channel
+    c->pitch = ((padded * c->esz + 4095) / 4096) * 4096 + 256;
+    if (const char *e = std::getenv("MSGW_PITCH_SKEW")) c->pitch += 256 * (size_t)std::atoi(e);
+    CR(hipMalloc(&c->slab, c->pitch * A_COUNT));
+    for (int k = 0; k < A_COUNT; ++k) *rp[k] = c->slab + (size_t)k * c->pitch;
     // column: one allocation carved into equally sized slots of ng doubles (+ 2 for the flux output)
     const size_t slot = (size_t)ngrid + 2;
     const int nslots = 24;
@@ -1113,7 +1109,7 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     // on c->stream, NOT the null stream: c->stream is non-blocking, so a null-stream fill (asynchronous to the
     // host for device memory) could land after msgw_set_column's uploads and wipe them
     CR(hipMemsetAsync(c->colbuf, 0, slot * nslots * sizeof(double) * 2, c->stream));
-    for (void *p : c->ray_bufs) CR(hipMemsetAsync(p, 0, padded * c->esz, c->stream));
+    CR(hipMemsetAsync(c->slab, 0, c->pitch * A_COUNT, c->stream));
     CR(hipStreamSynchronize(c->stream));
     double *b = c->colbuf;
     c->grid = b; b += slot; c->grids = b; b += slot; c->rhobar = b; b += slot;
@@ -1149,6 +1145,7 @@ int msgw_destroy(msgw_ctx *c)
     xch_teardown(c);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     for (void *p : c->ray_bufs) (void)hipFree(p);
+    if (c->slab) (void)hipFree(c->slab);
     if (c->colbuf) (void)hipFree(c->colbuf);
     if (c->partial) (void)hipFree(c->partial);
     if (c->ranges) (void)hipFree(c->ranges);
@@ -1815,6 +1812,15 @@ void xch_setup(msgw_ctx *c, const void *id128, std::string &why, int want_direct
         (void)xch_agree_rccl(c, false);
     }
     if (!ok && why.empty()) why = "another rank failed";
+    if (ok) {                                                  // what the persistent kernel's exchange workgroup reads
+        XchArgs x{};                                           // (everything but the per-launch sequence number)
+        x.nranks = c->nranks; x.rank = c->rank; x.stride = c->xch_stride; x.direct = c->xch_direct ? 1 : 0;
+        x.rows = c->xch_rows; x.flags = c->xch_flags;
+        x.peer_rows = c->xch_peer_rows; x.peer_flags = c->xch_peer_flags;
+        x.timeout_ticks = XCH_TIMEOUT_TICKS;
+        ok = hipMemcpy(c->xch_scratch + 16, &x, sizeof x, hipMemcpyHostToDevice) == hipSuccess;
+        if (!ok) why = "hipMemcpy of the transport description";
+    }
     c->xch_ok = ok;
     if (!ok) xch_teardown(c);
 }

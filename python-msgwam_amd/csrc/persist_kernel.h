@@ -93,9 +93,9 @@ struct PersistArgsT {
     unsigned int opts;            // PERSIST_OPT_*
     int *status;                  // 0 ok, 1 a wait timed out
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
-    int has_xch;                  // several ranks: the node-level exchange runs (one extra workgroup)
-    XchArgs xch;                  // ... with this transport (by value: the launch is not waited for, so nothing the
-                                  // kernel reads may live in host memory that the call could leave behind)
+    const XchArgs *xch;           // several ranks: the node-level exchange runs (one extra workgroup) with this transport
+                                  // (device memory, written once when the communicator is set up); else nullptr
+    unsigned long long xch_seq;   // sequence number of this launch's flux 0, minus 1
     ColIn cin;                    // canonical column at entry
     ColOut cout;                  // canonical column at exit (workgroup 0)
     double *dudz, *dvdz, *slu, *slv;    // derived tables at exit (workgroup 0)
@@ -295,13 +295,13 @@ __device__ __forceinline__ void persist_reduce_final(const PersistArgsT<T> p, un
     const unsigned int par = f & 1u;
     const double tot = persist_sum_groups(p, f, ncols, tid);
     // several ranks: this is only the rank's row; the exchange workgroup turns it into the final one
-    double *dst = p.has_xch ? p.flux2 + 2 * ncols : p.flux2;
+    double *dst = p.xch ? p.flux2 + 2 * ncols : p.flux2;
     if (tid < ncols) st_agent(dst + (size_t)par * ncols + tid, tot);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for flux f+2
-        __hip_atomic_fetch_add(p.has_xch ? p.ready + PD_LOCAL : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(p.xch ? p.ready + PD_LOCAL : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -418,7 +418,8 @@ __device__ __forceinline__ void persist_exchange(const PersistArgsT<T> p, int *s
 {
     const int ncols = 2 * (p.s.ng - 2);
     const unsigned int nflux = 3u * (unsigned int)p.nsteps + 1u;
-    const XchArgs x = p.xch;
+    XchArgs x = *p.xch;
+    x.seq = p.xch_seq;
     const double *flux_local = p.flux2 + 2 * ncols;
     for (unsigned int f = 0; f < nflux; ++f) {
         const unsigned int par = f & 1u;
@@ -506,7 +507,7 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgsT<T> p, const
     const int ncols = 2 * (ng - 2);
     for (unsigned int f = 0; f < nflux; ++f) {
         // pass q = f+1 is RK stage q % 3, column stage (q+2) % 3 = f % 3
-        if (p.has_xch) {                                       // several ranks: the exchange workgroup's final row
+        if (p.xch) {                                       // several ranks: the exchange workgroup's final row
             if (!persist_wait(p, f + 1u, L.flag, tid, p.ready + PD_ROW)) return;
             persist_column(p, L, f + 1u, (int)(f % 3u), tid);
         } else {                                               // one rank: add the reducers' group sums right here
@@ -684,9 +685,9 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
 #pragma unroll
         for (int i = 0; i < NRES; ++i) {
             if (res[i].v[0]) {
-                storev(a.r.rr, res[i].off, res[i].rr);
-                storev(a.r.mm, res[i].off, res[i].mm);
-                if (SAT || DIRECT || RL) storev(a.r.dens, res[i].off, res[i].dens);
+                storev(a.r.rr(), res[i].off, res[i].rr);
+                storev(a.r.mm(), res[i].off, res[i].mm);
+                if (SAT || DIRECT || RL) storev(a.r.dens(), res[i].off, res[i].dens);
             }
         }
     }

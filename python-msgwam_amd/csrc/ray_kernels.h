@@ -18,18 +18,42 @@ constexpr int SPAN_MAX = 8;          // widest per-wave level span on the shuffl
 constexpr int COL_BLOCK = 1024;      // the column kernel is one workgroup
 constexpr int FUSE_ROWS = 16;        // most dense flux rows the fused prologue adds up (= reduce-1 groups)
 
+// All per-ray arrays live in ONE slab, array k at slab + k * pitch: a kernel keeps one base pointer and the pitch in
+// SGPRs instead of one 64-bit pointer per array (19 pairs: with them the persistent kernel spilled SGPRs in its
+// hottest loop).  The k * pitch term is made opaque at every use so that the compiler re-forms it with a few SALU
+// instructions instead of hoisting 19 loop-invariant pointers and spilling them again.
+enum RayArray { A_DENS, A_RR, A_MM, A_DRR, A_KK, A_LL, A_DMM, A_VOL, A_FRAY, A_PVF, A_Q_RR, A_Q_MM, A_Q_DENS, A_RR0, A_MM0,
+                A_SRC_DENS, A_SRC_RR, A_SRC_MM, A_CG, A_COUNT };
 template <typename T>
 struct RayPtrsT {
-    T *dens, *rr, *mm;                             // evolving slots 0, 3, 7
-    const T *drr, *kk, *ll, *dmm;                  // frozen slots 4, 5, 6, 8 (HPROP off)
-    const T *vol;                                  // |dkk*dll*dmm|            (:137)
-    const T *fray;                                 // 2*Omega*sin(phi) per ray (:382)
-    const T *pvf;                                  // dkk*dll*(rr_mm_area/drr) (:594, :599)
-    T *q_rr, *q_mm, *q_dens;                       // low-storage RK registers
-    T *rr0, *mm0;                                  // start-of-step copies (direct saturation)
-    const T *src_dens, *src_rr, *src_mm;           // EXTENSION: source values for MSGW_RELAUNCH
-    T *cg;                                         // cg_rr of the current state (persistent kernel with resident
-                                                   // tiles: carried from the pass that produced the state)
+    char *slab;
+    unsigned int pitch256;                          // bytes between two arrays / 256
+    template <int K> __device__ __forceinline__ T *at() const
+    {
+        unsigned int p = pitch256;
+        asm volatile("" : "+s"(p));
+        const unsigned int t = (unsigned int)K * p;
+        return reinterpret_cast<T *>(slab + (((unsigned long long)t) << 8));
+    }
+    __device__ __forceinline__ T *dens() const { return at<A_DENS>(); }
+    __device__ __forceinline__ T *rr() const { return at<A_RR>(); }
+    __device__ __forceinline__ T *mm() const { return at<A_MM>(); }
+    __device__ __forceinline__ const T *drr() const { return at<A_DRR>(); }
+    __device__ __forceinline__ const T *kk() const { return at<A_KK>(); }
+    __device__ __forceinline__ const T *ll() const { return at<A_LL>(); }
+    __device__ __forceinline__ const T *dmm() const { return at<A_DMM>(); }
+    __device__ __forceinline__ const T *vol() const { return at<A_VOL>(); }
+    __device__ __forceinline__ const T *fray() const { return at<A_FRAY>(); }
+    __device__ __forceinline__ const T *pvf() const { return at<A_PVF>(); }
+    __device__ __forceinline__ T *q_rr() const { return at<A_Q_RR>(); }
+    __device__ __forceinline__ T *q_mm() const { return at<A_Q_MM>(); }
+    __device__ __forceinline__ T *q_dens() const { return at<A_Q_DENS>(); }
+    __device__ __forceinline__ T *rr0() const { return at<A_RR0>(); }
+    __device__ __forceinline__ T *mm0() const { return at<A_MM0>(); }
+    __device__ __forceinline__ const T *src_dens() const { return at<A_SRC_DENS>(); }
+    __device__ __forceinline__ const T *src_rr() const { return at<A_SRC_RR>(); }
+    __device__ __forceinline__ const T *src_mm() const { return at<A_SRC_MM>(); }
+    __device__ __forceinline__ T *cg() const { return at<A_CG>(); }
 };
 typedef RayPtrsT<double> RayPtrs;
 
@@ -553,27 +577,27 @@ __device__ __forceinline__ void load_tile(TileRegs<T> &t, const StageArgsT<T> a,
     t.off = (unsigned int)(i0 * (long long)sizeof(T));
 #pragma unroll
     for (int r = 0; r < RPT; ++r) t.v[r] = i0 + r < end;
-    loadv(a.r.rr, t.off, t.rr);
-    loadv(a.r.mm, t.off, t.mm);
-    loadv(a.r.kk, t.off, t.kk);
-    loadv(a.r.ll, t.off, t.ll);
-    if (DEPOSIT || SAT || (DIRECT && STAGE == 2)) loadv(a.r.dens, t.off, t.dens);
+    loadv(a.r.rr(), t.off, t.rr);
+    loadv(a.r.mm(), t.off, t.mm);
+    loadv(a.r.kk(), t.off, t.kk);
+    loadv(a.r.ll(), t.off, t.ll);
+    if (DEPOSIT || SAT || (DIRECT && STAGE == 2)) loadv(a.r.dens(), t.off, t.dens);
     if (DEPOSIT) {
-        loadv(a.r.drr, t.off, t.drr);
-        loadv(a.r.vol, t.off, t.vol);
+        loadv(a.r.drr(), t.off, t.drr);
+        loadv(a.r.vol(), t.off, t.vol);
     }
-    if (FVEC) loadv(a.r.fray, t.off, t.ff);
-    if (NEED_RHO) loadv(a.r.pvf, t.off, t.pvf);
+    if (FVEC) loadv(a.r.fray(), t.off, t.ff);
+    if (NEED_RHO) loadv(a.r.pvf(), t.off, t.pvf);
     if (STAGE == 1 || STAGE == 2) {
-        loadv(a.r.q_rr, t.off, t.qr);
-        loadv(a.r.q_mm, t.off, t.qm);
-        if (SAT) loadv(a.r.q_dens, t.off, t.qd);
+        loadv(a.r.q_rr(), t.off, t.qr);
+        loadv(a.r.q_mm(), t.off, t.qm);
+        if (SAT) loadv(a.r.q_dens(), t.off, t.qd);
     }
     if (DIRECT && STAGE == 2) {
-        loadv(a.r.rr0, t.off, t.rr0);
-        loadv(a.r.mm0, t.off, t.mm0);
+        loadv(a.r.rr0(), t.off, t.rr0);
+        loadv(a.r.mm0(), t.off, t.mm0);
     }
-    if (CGMEM) loadv(a.r.cg, t.off, t.cg);
+    if (CGMEM) loadv(a.r.cg(), t.off, t.cg);
 }
 
 // LDS views shared by the stage kernels
@@ -712,9 +736,9 @@ __device__ __forceinline__ void deposit_pass(const StageArgsT<T> a, const StageL
 #pragma unroll
         for (int r = 0; r < RPT; ++r) valid[r] = e0 + r < end;
         T rr[RPT], mm[RPT], kk[RPT], ll[RPT], dens[RPT], drr[RPT], vol[RPT], ff[RPT];
-        loadv(a.r.rr, off, rr); loadv(a.r.mm, off, mm); loadv(a.r.kk, off, kk); loadv(a.r.ll, off, ll);
-        loadv(a.r.dens, off, dens); loadv(a.r.drr, off, drr); loadv(a.r.vol, off, vol);
-        if (FVEC) loadv(a.r.fray, off, ff);
+        loadv(a.r.rr(), off, rr); loadv(a.r.mm(), off, mm); loadv(a.r.kk(), off, kk); loadv(a.r.ll(), off, ll);
+        loadv(a.r.dens(), off, dens); loadv(a.r.drr(), off, drr); loadv(a.r.vol(), off, vol);
+        if (FVEC) loadv(a.r.fray(), off, ff);
         T lo[RPT], up[RPT], pay[2][RPT], cg2[RPT];
         int nlo[RPT], nup[RPT];
 #pragma unroll
@@ -729,7 +753,7 @@ __device__ __forceinline__ void deposit_pass(const StageArgsT<T> a, const StageL
             pay[0][r] = cgr * kk[r] * dens[r];
             pay[1][r] = cgr * ll[r] * dens[r];
         }
-        if (CGSTORE && valid[0] && base >= cg_from) storev(a.r.cg, off, cg2);   // streamed tiles of the persistent kernel
+        if (CGSTORE && valid[0] && base >= cg_from) storev(a.r.cg(), off, cg2);   // streamed tiles of the persistent kernel
         deposit_tile<2, NH, T>(lo, up, nlo, nup, vol, pay, L.gs, a.dzs, a.inv_dzs, a.mk_ok,
                                L.rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
     }
@@ -906,19 +930,19 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgsT<T> a)
         const unsigned int i0 = (unsigned int)(e0 * (long long)sizeof(T));
         const bool own = e0 < end;
         T rr[RPT], mm[RPT], kk[RPT], ll[RPT], dens[RPT], ff[RPT], pvf[RPT];
-        loadv(a.r.rr, i0, rr);
-        loadv(a.r.mm, i0, mm);
-        loadv(a.r.kk, i0, kk);
-        loadv(a.r.ll, i0, ll);
-        if (FVEC) loadv(a.r.fray, i0, ff);
-        if (NEED_RHO) { loadv(a.r.dens, i0, dens); loadv(a.r.pvf, i0, pvf); }
+        loadv(a.r.rr(), i0, rr);
+        loadv(a.r.mm(), i0, mm);
+        loadv(a.r.kk(), i0, kk);
+        loadv(a.r.ll(), i0, ll);
+        if (FVEC) loadv(a.r.fray(), i0, ff);
+        if (NEED_RHO) { loadv(a.r.dens(), i0, dens); loadv(a.r.pvf(), i0, pvf); }
         T sd[RPT], sr[RPT], sm[RPT], drr[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) { sd[r] = T(0); sr[r] = T(0); sm[r] = T(0); drr[r] = T(0); }
         if (a.relaunch) {                                     // workgroup-uniform
-            loadv(a.r.src_dens, i0, sd); loadv(a.r.src_rr, i0, sr); loadv(a.r.src_mm, i0, sm);
-            loadv(a.r.drr, i0, drr);
-            if (!NEED_RHO) loadv(a.r.dens, i0, dens);
+            loadv(a.r.src_dens(), i0, sd); loadv(a.r.src_rr(), i0, sr); loadv(a.r.src_mm(), i0, sm);
+            loadv(a.r.drr(), i0, drr);
+            if (!NEED_RHO) loadv(a.r.dens(), i0, dens);
         }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
@@ -984,9 +1008,9 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgsT<T> a)
           }
         }
         if (own) {
-            storev(a.r.rr, i0, rr);
-            storev(a.r.mm, i0, mm);
-            if (NEED_RHO || a.relaunch) storev(a.r.dens, i0, dens);
+            storev(a.r.rr(), i0, rr);
+            storev(a.r.mm(), i0, mm);
+            if (NEED_RHO || a.relaunch) storev(a.r.dens(), i0, dens);
         }
     }
 }
@@ -1059,15 +1083,15 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
             }
         } else {
             T rr[RPT], mm[RPT], drr[RPT], dmm[RPT];
-            loadv(a.r.rr, i0, rr);
-            loadv(a.r.mm, i0, mm);
-            loadv(a.r.kk, i0, kk);
-            loadv(a.r.ll, i0, ll);
-            loadv(a.r.dens, i0, dens);
-            loadv(a.r.drr, i0, drr);
-            loadv(a.r.dmm, i0, dmm);
-            loadv(a.r.vol, i0, vol);
-            if (FVEC) loadv(a.r.fray, i0, ff);
+            loadv(a.r.rr(), i0, rr);
+            loadv(a.r.mm(), i0, mm);
+            loadv(a.r.kk(), i0, kk);
+            loadv(a.r.ll(), i0, ll);
+            loadv(a.r.dens(), i0, dens);
+            loadv(a.r.drr(), i0, drr);
+            loadv(a.r.dmm(), i0, dmm);
+            loadv(a.r.vol(), i0, vol);
+            if (FVEC) loadv(a.r.fray(), i0, ff);
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
                 lo[r] = rr[r] - T(.5) * drr[r];                       // :655 / raytracer.py:200-201
