@@ -278,21 +278,27 @@ int ensure_lds(msgw_ctx *c, const void *kernel, size_t bytes)
 }
 
 // Launch geometry: every workgroup owns `rays_per_block` contiguous rays, a whole number of
-// tiles (512 float64 / 1024 float32 rays), at most ncu*blocks_per_cu workgroups.  (A finer split that
-// balances the workgroups exactly over the CUs -- 1009 x 992 rays instead of 977 x 1024 at 1e6 rays -- was
-// measured: no gain for the per-stage kernels, 4 % slower for the persistent kernel, whose
-// synchronisation cost grows with the number of workgroups.)
-void geometry(msgw_ctx *c, int64_t n)
+// tiles (512 float64 / 1024 float32 rays), at most ncu*blocks_per_cu workgroups.  Measured and dropped:
+//  * a finer split of whole tiles that balances the workgroups exactly over the CUs (1009 x 992 rays instead of
+//    977 x 1024 at 1e6 rays): no gain for the per-stage kernels, 4 % slower for the persistent kernel, whose
+//    synchronisation cost grows with the number of workgroups (round 1);
+//  * ranges of whole WAVE quanta (a quarter tile) with wavefronts skipping the empty part of a workgroup's last
+//    tile, so that 1.25e6 float32 rays make 1024 workgroups of ~1.2 tiles instead of 611 of two: 59 -> 71 us per
+//    step with all rays streamed, 113 -> 129 us for the launch chain (more workgroups to synchronise, and a lone
+//    wavefront in a partly empty tile has nothing to hide its latency behind).
+void split_rays(const msgw_ctx *c, int64_t n, int64_t maxb, int64_t *rays_per_block, int *tiles_per_block, int *blocks)
 {
     const int64_t ntiles = (n + c->tile - 1) / c->tile;
-    const int64_t maxb = (int64_t)c->ncu * c->blocks_per_cu;
+    if (maxb < 1) maxb = 1;
     int64_t tpb = (ntiles + maxb - 1) / maxb;
     if (tpb < 1) tpb = 1;
-    int64_t blocks = (ntiles + tpb - 1) / tpb;
-    if (blocks < 1) blocks = 1;
-    c->tiles_per_block = (int)tpb;
-    c->rays_per_block = tpb * c->tile;
-    c->blocks = (int)blocks;
+    *tiles_per_block = (int)tpb;
+    *rays_per_block = tpb * c->tile;
+    *blocks = (int)std::max<int64_t>((ntiles + tpb - 1) / tpb, 1);
+}
+void geometry(msgw_ctx *c, int64_t n)
+{
+    split_rays(c, n, (int64_t)c->ncu * c->blocks_per_cu, &c->rays_per_block, &c->tiles_per_block, &c->blocks);
 }
 
 void drop_graph(msgw_ctx *c)
@@ -627,16 +633,12 @@ int plan_persist(msgw_ctx *c, int nres, int mode, bool rl, bool multi, PersistPl
     if (nres > 0) {
         // own geometry: as many ray workgroups as fit beside 16 reducers, the column and the exchange
         // workgroup at this kernel's occupancy (2 per CU)
-        const long long ntiles = (c->n + c->tile - 1) / c->tile;
         const long long maxb = slots - (16 + 2);
         if (maxb < 1) return MSGW_OK;
-        const long long tpb = std::max<long long>((ntiles + maxb - 1) / maxb, 1);
+        split_rays(c, c->n, maxb, &pl.rays_per_block, &pl.tiles_per_block, &blocks);
         // measured with 2 resident tiles: +10 % at 2e6 rays (8 tiles per workgroup), +3 % at 4e6 and 8e6 (16, 32),
         // -10 % at 16e6 (64), where 4 workgroups per CU with all rays streamed are better
-        if (tpb > 16 * nres) return MSGW_OK;
-        blocks = (int)((ntiles + tpb - 1) / tpb);
-        pl.tiles_per_block = (int)tpb;
-        pl.rays_per_block = tpb * c->tile;
+        if (pl.tiles_per_block > 16 * nres) return MSGW_OK;
     }
     pl.blocks = blocks;
     const int max_groups = nres > 0 ? 16 : PERSIST_GROUPS;

@@ -275,6 +275,7 @@ __device__ __forceinline__ T np_trunc_index(T t)
 template <typename T>
 __device__ __forceinline__ T div_const(T x, T d, T c, int ok)
 {
+    if constexpr (std::is_same<T, float>::value) return x * c;   // float32: no bit-level pin (see real.h)
     if (!ok) return x / d;
     const T q = x * c;
     const T r = fma(-d, q, x);
@@ -537,15 +538,15 @@ __device__ __forceinline__ void dispersion(T kk, T ll, T mm, T f2, T bvf2, T &kh
     kh2 = kk * kk + ll * ll;
     m2 = mm * mm;
     vk2 = kh2 + m2;
-    om = sqrt((bvf2 * kh2 + f2 * m2) / vk2);
-    cgr = -mm * (om * om - f2) / om / vk2;
+    om = sqrt_(div_(bvf2 * kh2 + f2 * m2, vk2));
+    cgr = div_(div_(-mm * (om * om - f2), om), vk2);
 }
 
 // saturation cap :601 (rho_f already interpolated)
 template <typename T>
 __device__ __forceinline__ T sat_cap(T sat_c, T rho_f, T omh, T bvf2, T mm_f, T f0sq)
 {
-    return sat_c * rho_f * omh * bvf2 / (mm_f * mm_f) / (omh * omh - f0sq);
+    return div_(div_(sat_c * rho_f * omh * bvf2, mm_f * mm_f), omh * omh - f0sq);
 }
 
 // ------------------------------------------------------------------ K1: one RK stage over the rays
@@ -956,8 +957,8 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgsT<T> a)
             for (int st = 0; st < 3; ++st) {
                 const T m2 = mm[r] * mm[r];
                 const T vk2 = kh2 + m2;
-                const T om = sqrt((a.bvf2 * kh2 + f2 * m2) / vk2);
-                const T cgr = -mm[r] * (om * om - f2) / om / vk2;
+                const T om = sqrt_(div_(a.bvf2 * kh2 + f2 * m2, vk2));
+                const T cgr = div_(div_(-mm[r] * (om * om - f2), om), vk2);
                 const T st_rr = T(.5) * (cgr + cgr);
                 const Bracket<T> bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
                 const quad_t sh = s_sh[bk.j];
@@ -971,9 +972,9 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgsT<T> a)
                     const Bracket<T> br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
                     const pair_t rh = s_rho2[br.j];                                    // {rhobar, slope}
                     const T rho_f = interp_eval(rr_f, br, rh.x, rh.y);        // :595
-                    const T omh = a.same_f ? om : sqrt((a.bvf2 * kh2 + a.f0sq * m2) / vk2);
+                    const T omh = a.same_f ? om : sqrt_(div_(a.bvf2 * kh2 + a.f0sq * m2, vk2));
                     const T maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
-                    if (maxd < dens[r] * pvf[r]) st_dens = (maxd - dens[r]) / a.dt;
+                    if (maxd < dens[r] * pvf[r]) st_dens = div_(maxd - dens[r], a.dt);
                 }
                 if (st == 0) {
                     q_r = a.dt * st_rr; q_m = a.dt * st_mm;
@@ -988,15 +989,15 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgsT<T> a)
                 }
             }
             if (DIRECT) {
-                const T rr_st = (rr[r] - rr_old) / a.sat_rr_div;
-                const T mm_st = (mm[r] - mm_old) / a.dt;
+                const T rr_st = div_(rr[r] - rr_old, a.sat_rr_div);
+                const T mm_st = div_(mm[r] - mm_old, a.dt);
                 const T rr_f = rr_old + rr_st * a.dt;
                 const T mm_f = mm_old + mm_st * a.dt;
                 const Bracket<T> br = interp_locate(rr_f, s_gs, nc, a.gs0, a.gs_last, a.gs0, a.inv_dzs);
                 const pair_t rh = s_rho2[br.j];                                    // {rhobar, slope}
                 const T rho_f = interp_eval(rr_f, br, rh.x, rh.y);        // :595
                 const T m02 = mm_old * mm_old;
-                const T omh = sqrt((a.bvf2 * kh2 + a.f0sq * m02) / (kh2 + m02));
+                const T omh = sqrt_(div_(a.bvf2 * kh2 + a.f0sq * m02, kh2 + m02));
                 const T maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);
                 if (maxd < dens[r] * pvf[r]) dens[r] = maxd;
             }
