@@ -2,8 +2,10 @@
 
 The development box has ONE GPU, so the ranks of these tests share it: each rank is its own
 process with its own HIP context, rays sharded, column replicated, exactly as on an 8-GPU node;
-only the PCIe endpoints coincide.  RCCL refuses two ranks on one device, so the ranks are set up
-with MSGW_EXCHANGE_ONLY=1 (no RCCL communicator; the shared segment is the only link)."""
+only the memory the peers' IPC mappings point at coincides (one HBM instead of eight linked by xGMI).
+RCCL refuses two ranks on one device, so the ranks are set up with MSGW_EXCHANGE_ONLY=1 (no RCCL
+communicator; the exchange buffers are the only link).  Both transports are exercised: the
+device-resident one (default) and the host-segment fallback (MSGW_XCH_TRANSPORT=shm)."""
 import os
 import subprocess
 import sys
@@ -11,6 +13,8 @@ import sys
 import numpy as np
 import pytest
 
+from oracle import msgwam_oracle as orc
+from oracle.c_oracle import COracle
 from gpu_helpers import make_prop, gpu_state
 from helpers import STATE_KEYS
 from msgwam_amd import _capi
@@ -34,7 +38,7 @@ def test_exchange_with_one_rank_is_bitwise_the_single_gpu_path(monkeypatch):
     monkeypatch.setenv("MSGW_FORCE_COLLECTIVE", "1")
     p = make_prop(s, st)
     p.comm_init(_capi.comm_unique_id(), 0, 1)
-    assert p.counters()["exchange"] == 1
+    assert p.counters()["exchange"] == 1 and p.counters()["transport"] == 3    # device-resident (HIP IPC) transport
     p.step(60.0, 2)
     p.step(60.0, 7)
     assert p.counters()["persist_steps"] == 7
@@ -56,52 +60,137 @@ def test_exchange_off_falls_back_to_the_allreduce_chain(monkeypatch):
     p.close()
 
 
-@pytest.mark.parametrize("nranks,n,sat,flags", [(2, 120_000, False, 0), (3, 50_001, False, 0),
-                                                 (2, 90_001, True, 0), (2, 70_000, False, _capi.DIRECT_SAT)])
-def test_ranks_as_processes_sharing_the_gpu(tmp_path, nranks, n, sat, flags):
-    """nranks processes, each with its shard of the rays, advance together through the in-kernel
-    exchange.  Against ONE process with all rays: per-ray state and column within summation-order
-    noise (the ranks' partial sums are grouped differently), and the replicated columns of the ranks
-    BITWISE equal to each other (every rank adds the same rows in the same order)."""
-    s, st = _random_case(n, 70 + nranks, sat, "uniform", True)
-    st[0] = st[0] * 1e-3                               # mild forcing: well-posed comparison
-    calls = np.array([1, 2, 6])
-    ref = make_prop(s, st)
-    for k in calls:
-        ref.step(60.0, int(k), flags)
-    want = gpu_state(ref, st)
-    ref.close()
-    dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = st
-    case = tmp_path / "case.npz"
-    np.savez(case, grid=s.grid, grids=s.grids, rhobar=s.rhobar, pg=s.pressure_gradient, uu=uu, vv=vv, dens=dens,
-             rr=rr, drr=drr, kk=kk, ll=ll, mm=mm, dmm=dmm, phi=phi, dkk=np.broadcast_to(s.dkk, (n,)),
-             dll=np.broadcast_to(s.dll, (n,)), area=np.broadcast_to(s.rr_mm_area, (n,)), bvf=s.bvf, phi0=s.phi0,
-             kappa=s.kappa, sat=s.saturate_online, dt=60.0, calls=calls, flags=flags)
+def _run_ranks(tmp_path, case, nranks, env_extra=None, per_rank_env=None, timeout=240):
+    """Start one worker process per rank on the shared GPU; returns (return codes, logs, outputs)."""
     uid = _capi.comm_unique_id().hex()
-    env = dict(os.environ, MSGW_EXCHANGE_ONLY="1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "xch_rank_worker.py"), str(case), str(r),
-                               str(nranks), uid, str(tmp_path / f"out{r}.npz")], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(nranks)]
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, MSGW_EXCHANGE_ONLY="1")
+        env.update(env_extra or {})
+        env.update((per_rank_env or {}).get(r, {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "xch_rank_worker.py"), str(case), str(r),
+                                       str(nranks), uid, str(tmp_path / f"out{r}.npz")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     try:
         for pr in procs:
-            out, _ = pr.communicate(timeout=240)
+            out, _ = pr.communicate(timeout=timeout)
             logs.append(out.decode(errors="replace"))
     finally:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()                              # exact children only
-    assert all(pr.returncode == 0 for pr in procs), "\n".join(logs)
-    outs = [np.load(tmp_path / f"out{r}.npz") for r in range(nranks)]
+    codes = [pr.returncode for pr in procs]
+    outs = [np.load(tmp_path / f"out{r}.npz") if codes[r] == 0 else None for r in range(nranks)]
+    return codes, logs, outs
+
+
+def _save_case(path, s, st, n, calls, flags, dtype="f64", dt=60.0, **extra):
+    dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = st
+    np.savez(path, grid=s.grid, grids=s.grids, rhobar=s.rhobar, pg=s.pressure_gradient, uu=uu, vv=vv, dens=dens,
+             rr=rr, drr=drr, kk=kk, ll=ll, mm=mm, dmm=dmm, phi=phi, dkk=np.broadcast_to(s.dkk, (n,)),
+             dll=np.broadcast_to(s.dll, (n,)), area=np.broadcast_to(s.rr_mm_area, (n,)), bvf=s.bvf, phi0=s.phi0,
+             kappa=s.kappa, sat=s.saturate_online, dt=dt, calls=calls, flags=flags, dtype=dtype, **extra)
+
+
+@pytest.mark.parametrize("nranks,n,sat,flags,transport", [
+    (2, 120_000, False, 0, "device_ipc"), (3, 50_001, False, 0, "device_ipc"), (2, 90_001, True, 0, "device_ipc"),
+    (2, 70_000, False, _capi.DIRECT_SAT, "device_ipc"), (2, 120_000, False, 0, "host_shm"), (3, 50_001, True, 0, "host_shm")])
+def test_ranks_as_processes_sharing_the_gpu(tmp_path, nranks, n, sat, flags, transport):
+    """nranks processes, each with its shard of the rays, advance together through the in-kernel exchange, over
+    the device-resident transport (every rank writes its row into the HIP-IPC-mapped buffers of all ranks) and
+    over the host-segment fallback.  The concatenated shards are held to the C ORACLE run on the full ray set
+    (rtol 1e-10: the ranks' partial sums are grouped differently from any single-process order), and the
+    replicated columns of the ranks must be BITWISE equal to each other (every rank adds the same rows in rank
+    order)."""
+    s, st = _random_case(n, 70 + nranks, sat, "uniform", True)
+    st[0] = st[0] * 1e-3                               # mild forcing: well-posed comparison
+    calls = np.array([1, 2, 6])
+    want = COracle(s).step(60.0, int(calls.sum()), st, direct_sat=2 if flags & _capi.DIRECT_SAT else 0)
+    case = tmp_path / "case.npz"
+    _save_case(case, s, st, n, calls, flags)
+    codes, logs, outs = _run_ranks(tmp_path, case, nranks,
+                                   {"MSGW_XCH_TRANSPORT": "shm"} if transport == "host_shm" else None)
+    assert all(c == 0 for c in codes), "\n".join(logs)
     for o in outs:
-        assert int(o["exchange"]) == 1
+        assert int(o["exchange"]) == 1 and _capi.TRANSPORTS[int(o["transport"])] == transport
+        assert int(o["tenants"]) == nranks                 # the ranks found out that they share one device
         assert list(o["persist"]) == list(calls)       # every call was ONE persistent launch
         assert np.array_equal(o["uu"], outs[0]["uu"]) and np.array_equal(o["vv"], outs[0]["vv"])
     got = [np.asarray(x, dtype=np.float64).copy() for x in st]
     for i, k in ((0, "dens"), (3, "rr"), (7, "mm")):
         got[i] = np.concatenate([o[k] for o in outs])
     got[9], got[10] = outs[0]["uu"], outs[0]["vv"]
-    check_state(got, want, 1e-10, 1e-11, f"{nranks} ranks vs one")
+    check_state(got, want, 1e-10, 1e-11, f"{nranks} ranks vs the oracle")
+
+
+def test_two_ranks_float32_saturation_and_relaunch_vs_oracle(tmp_path):
+    """BASELINE config 5's kernel variant (float32 state, online saturation, relaunch extension) on two ranks that
+    exchange their flux rows inside the persistent kernel, against the float64 oracle's step -> relaunch loop on
+    the full ray set (float32 tolerances, see test_gpu_f32.py)."""
+    from test_gpu_f32 import _spectrum_case, check32
+    n = 200_000
+    s, st = _spectrum_case(n, 0.01, True, kappa=0.008)
+    src = (st[0].copy(), st[3].copy(), st[7].copy())
+    co = COracle(s)
+    want, recycled = st, 0
+    for _ in range(3):
+        want = co.step(120.0, 1, want)
+        want, mask = orc.relaunch(s, want, src, 0.5)
+        recycled += int(mask.sum())
+    assert recycled > 1000
+    case = tmp_path / "case.npz"
+    _save_case(case, s, st, n, np.array([1, 2]), _capi.RELAUNCH, dtype="f32", dt=120.0, relaunch_frac=0.5)
+    codes, logs, outs = _run_ranks(tmp_path, case, 2)
+    assert all(c == 0 for c in codes), "\n".join(logs)
+    assert all(list(o["persist"]) == [1, 2] for o in outs)
+    assert np.array_equal(outs[0]["uu"], outs[1]["uu"])
+    got = [np.asarray(x, dtype=np.float64).copy() for x in st]
+    for i, k in ((0, "dens"), (3, "rr"), (7, "mm")):
+        got[i] = np.concatenate([o[k] for o in outs])
+    got[9], got[10] = outs[0]["uu"], outs[0]["vv"]
+    check32(got, want, 1e-4, 1e-4, "2 ranks f32", outliers=1e-3)
+
+
+@pytest.mark.parametrize("per_rank_env", [{0: {"MSGW_PERSIST": "0"}, 1: {"MSGW_PERSIST": "0"}}, {1: {"MSGW_PERSIST": "0"}}])
+def test_ranks_without_rccl_fail_loudly_when_a_step_leaves_the_persistent_kernel(tmp_path, per_rank_env):
+    """A communicator without RCCL (MSGW_EXCHANGE_ONLY=1) can only sum the ranks' rows inside the persistent
+    kernel.  When a step cannot take it -- here MSGW_PERSIST=0 on both ranks, or on ONE rank only (the ranks agree
+    on the path through the segment before anything is launched, so the other rank does not spin into its
+    time-out) -- every rank must raise instead of advancing its column with its local flux."""
+    import time
+    s, st = _random_case(40_000, 75, False, "uniform", True)
+    case = tmp_path / "case.npz"
+    _save_case(case, s, st, 40_000, np.array([2]), 0)
+    t0 = time.perf_counter()
+    codes, logs, _ = _run_ranks(tmp_path, case, 2, per_rank_env=per_rank_env, timeout=120)
+    assert time.perf_counter() - t0 < 60                   # no rank waited for an exchange time-out (20 s per wait)
+    assert all(c != 0 for c in codes), "\n".join(logs)
+    assert all("without RCCL" in log for log in logs), "\n".join(logs)
+
+
+@pytest.mark.parametrize("transport", ["device_ipc", "host_shm"])
+def test_config4_shard_size_through_the_exchange_vs_c_oracle(monkeypatch, transport):
+    """BASELINE config 4's per-GPU shard (1.25e6 rays of the synthetic spectrum, float64, coupled) through the
+    multi-rank code path with a 1-rank communicator (MSGW_FORCE_COLLECTIVE=1: exchange workgroup, sequence
+    numbers, row through the transport and back) against the C oracle on every ray, 2 steps."""
+    from test_gpu_f32 import _spectrum_case
+    monkeypatch.setenv("MSGW_FORCE_COLLECTIVE", "1")
+    if transport == "host_shm":
+        monkeypatch.setenv("MSGW_XCH_TRANSPORT", "shm")
+    n = 1_250_000
+    s, st = _spectrum_case(n, 0.01, False)
+    want = COracle(s).step(120.0, 2, st)
+    p = make_prop(s, st)
+    p.comm_init(_capi.comm_unique_id(), 0, 1)
+    c = p.counters()
+    assert c["exchange"] == 1 and _capi.TRANSPORTS[c["transport"]] == transport
+    p.step(120.0, 2)
+    assert p.counters()["persist_steps"] == 2
+    got = gpu_state(p, st)
+    p.close()
+    check_state(got, want, 1e-10, 1e-11, "config4 shard")
+    assert not np.array_equal(got[9], st[9])
 
 
 def test_bench_multi_rank_launch_rehearsal(tmp_path):

@@ -16,11 +16,14 @@ def main():
     n = len(d["dens"])
     lo, hi = shard_bounds(n, nranks, rank)
     sl = slice(lo, hi)
-    p = _capi.Propagator(len(d["grid"]), hi - lo)
+    dtype = str(d["dtype"]) if "dtype" in d.files else "f64"
+    p = _capi.Propagator(len(d["grid"]), hi - lo, dtype=dtype)
     p.set_config(float(d["bvf"]), float(d["phi0"]), float(d["kappa"]), bool(d["sat"]))
     p.set_column(d["grid"], d["grids"], d["rhobar"], d["pg"], d["uu"], d["vv"])
     p.upload_rays(d["dens"][sl], d["rr"][sl], d["drr"][sl], d["kk"][sl], d["ll"][sl], d["mm"][sl], d["dmm"][sl],
                   d["phi"][sl], d["dkk"][sl], d["dll"][sl], d["area"][sl])
+    if "relaunch_frac" in d.files:
+        p.set_relaunch(float(d["relaunch_frac"]))
     p.comm_init(bytes.fromhex(uid_hex), rank, nranks)
     cnt0 = p.counters()
     persist = []
@@ -30,7 +33,7 @@ def main():
     dens, rr, mm = p.download_rays()
     uu, vv = p.download_column()
     np.savez(out, dens=dens, rr=rr, mm=mm, uu=uu, vv=vv, lo=lo, hi=hi, exchange=cnt0["exchange"],
-             persist=np.array(persist))
+             transport=cnt0["transport"], tenants=cnt0["tenants"], persist=np.array(persist))
     p.close()
 
 
