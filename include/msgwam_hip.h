@@ -185,6 +185,17 @@ int msgw_saturation(msgw_ctx *ctx, int64_t n, double dt, int direct,
 int msgw_download_rays(msgw_ctx *ctx, int64_t n, double *dens, double *rr, double *mm);
 int msgw_download_column(msgw_ctx *ctx, double *uu, double *vv);
 
+/* Snapshots (no reference counterpart; serve the lazy host copies of the Python mirror): a
+ * stream-ordered device copy of the evolving slots -- dens, rr, mm, the uu, vv columns and, with HPROP on, lam, phi,
+ * kk, ll.  msgw_step does not wait for its kernels, so a caller that may never look at a state need not copy it to
+ * the host; if it does look later, after the resident state has moved on, the snapshot still has it.
+ * Download: any pointer may be NULL.  A snapshot must be destroyed before its context. */
+typedef struct msgw_snapshot msgw_snapshot;
+int msgw_snapshot_create(msgw_ctx *ctx, msgw_snapshot **out);
+int msgw_snapshot_download(msgw_ctx *ctx, msgw_snapshot *snap, double *dens, double *rr, double *mm,
+                           double *uu, double *vv, double *lam, double *phi, double *kk, double *ll);
+int msgw_snapshot_destroy(msgw_ctx *ctx, msgw_snapshot *snap);
+
 /* Wait for all queued work of this context. */
 int msgw_sync(msgw_ctx *ctx);
 

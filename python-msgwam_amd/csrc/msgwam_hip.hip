@@ -211,6 +211,8 @@ struct msgw_ctx {
     unsigned long long xch_calls = 0;         // per-call agreements done (xch_agree_step)
     char pci_id[16] = {0};
 
+    // snapshots of the evolving slots (msgw_snapshot_*): released buffers are kept for reuse
+    std::vector<std::pair<size_t, void *>> snap_pool;
     // counters / kernel timing
     msgw_counters_t cnt{};
     std::vector<hipEvent_t> kev;
@@ -1147,6 +1149,7 @@ int msgw_destroy(msgw_ctx *c)
     xch_teardown(c);
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     for (void *p : c->ray_bufs) (void)hipFree(p);
+    for (auto &sp : c->snap_pool) (void)hipFree(sp.second);
     if (c->slab) (void)hipFree(c->slab);
     if (c->colbuf) (void)hipFree(c->colbuf);
     if (c->partial) (void)hipFree(c->partial);
@@ -1541,6 +1544,90 @@ int msgw_download_column(msgw_ctx *c, double *uu, double *vv)
     if (uu) HIPCHK(c, hipMemcpyAsync(uu, c->uu, B, hipMemcpyDeviceToHost, c->stream));
     if (vv) HIPCHK(c, hipMemcpyAsync(vv, c->vv, B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSGW_OK;
+}
+
+// ---- snapshots: a stream-ordered device copy of the evolving slots, for host mirrors that hand out results lazily
+// (msgwam_amd/libprop.py: the arrays RK3 returns are downloaded on first access; a state that is advanced before it
+// was read stays readable through its snapshot).  ~24 MB of device copies per 1e6 float64 rays.
+struct msgw_snapshot {
+    void *buf = nullptr;
+    size_t bytes = 0;
+    int64_t n = 0;
+    int hprop = 0;
+};
+
+int msgw_snapshot_create(msgw_ctx *c, msgw_snapshot **out)
+{
+    if (!c || !out) return MSGW_ERR_ARG;
+    *out = nullptr;
+    if (!c->have_rays || !c->have_column) return fail(c, MSGW_ERR_ARG, "nothing resident to snapshot");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t ray = (size_t)c->n * c->esz, hp = (c->hprop && c->have_hprop) ? (size_t)c->n * sizeof(double) : 0;
+    const size_t col = (size_t)(c->ng - 1) * sizeof(double);
+    const size_t bytes = 3 * ray + 4 * hp + 2 * col;
+    msgw_snapshot *s = new msgw_snapshot();
+    for (size_t i = 0; i < c->snap_pool.size(); ++i)
+        if (c->snap_pool[i].first >= bytes) {
+            s->buf = c->snap_pool[i].second; s->bytes = c->snap_pool[i].first;
+            c->snap_pool.erase(c->snap_pool.begin() + i);
+            break;
+        }
+    if (!s->buf) {
+        if (hipMalloc(&s->buf, bytes) != hipSuccess) { delete s; return fail(c, MSGW_ERR_HIP, "hipMalloc of a snapshot failed"); }
+        s->bytes = bytes;
+    }
+    s->n = c->n; s->hprop = hp ? 1 : 0;
+    char *b = static_cast<char *>(s->buf);
+    const void *src[3] = {c->dens, c->rr, c->mm};
+    for (int i = 0; i < 3; ++i) HIPCHK(c, hipMemcpyAsync(b + i * ray, src[i], ray, hipMemcpyDeviceToDevice, c->stream));
+    b += 3 * ray;
+    if (hp) {
+        const void *hs[4] = {c->lam, c->phi, c->kk, c->ll};
+        for (int i = 0; i < 4; ++i) HIPCHK(c, hipMemcpyAsync(b + i * hp, hs[i], hp, hipMemcpyDeviceToDevice, c->stream));
+        b += 4 * hp;
+    }
+    HIPCHK(c, hipMemcpyAsync(b, c->uu, col, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + col, c->vv, col, hipMemcpyDeviceToDevice, c->stream));
+    *out = s;
+    return MSGW_OK;
+}
+
+int msgw_snapshot_download(msgw_ctx *c, msgw_snapshot *s, double *dens, double *rr, double *mm, double *uu, double *vv,
+                           double *lam, double *phi, double *kk, double *ll)
+{
+    if (!c || !s || !s->buf) return MSGW_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_status(c)) return rc;
+    const size_t ray = (size_t)s->n * c->esz, hp = s->hprop ? (size_t)s->n * sizeof(double) : 0;
+    const size_t col = (size_t)(c->ng - 1) * sizeof(double);
+    char *b = static_cast<char *>(s->buf);
+    Staging st;
+    if (c->f32 && (dens || rr || mm)) HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)s->n * 3));
+    double *dst[3] = {dens, rr, mm};
+    for (int i = 0; i < 3; ++i)
+        if (dst[i]) if (int rc = download_array(c, dst[i], b + i * ray, s->n, st.p ? st.p + (size_t)i * s->n : nullptr)) return rc;
+    b += 3 * ray;
+    if ((lam || phi || kk || ll) && !hp) return fail(c, MSGW_ERR_ARG, "this snapshot holds no HPROP slots");
+    double *hd[4] = {lam, phi, kk, ll};
+    for (int i = 0; i < 4; ++i)
+        if (hd[i]) HIPCHK(c, hipMemcpyAsync(hd[i], b + i * hp, hp, hipMemcpyDeviceToHost, c->stream));
+    b += 4 * hp;
+    if (uu) HIPCHK(c, hipMemcpyAsync(uu, b, col, hipMemcpyDeviceToHost, c->stream));
+    if (vv) HIPCHK(c, hipMemcpyAsync(vv, b + col, col, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSGW_OK;
+}
+
+int msgw_snapshot_destroy(msgw_ctx *c, msgw_snapshot *s)
+{
+    if (!s) return MSGW_OK;
+    if (c && s->buf) {
+        // reuse is stream-ordered: the next snapshot's copies are enqueued behind everything that read this buffer
+        if (c->snap_pool.size() < 8) c->snap_pool.emplace_back(s->bytes, s->buf);
+        else { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); (void)hipFree(s->buf); }
+    }
+    delete s;
     return MSGW_OK;
 }
 

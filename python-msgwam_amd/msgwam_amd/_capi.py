@@ -29,6 +29,7 @@ EXPORTS = [
     "msgw_set_column", "msgw_upload_rays", "msgw_step", "msgw_rhs", "msgw_project",
     "msgw_project_arrays", "msgw_saturation", "msgw_download_rays", "msgw_download_column",
     "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters", "msgw_set_relaunch", "msgw_upload_hprop", "msgw_download_hprop",
+    "msgw_snapshot_create", "msgw_snapshot_download", "msgw_snapshot_destroy",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -83,6 +84,9 @@ def load_library():
     lib.msgw_set_relaunch.argtypes = [C.c_void_p, C.c_double]
     lib.msgw_upload_hprop.argtypes = [C.c_void_p, C.c_int64, _dp, _dp]
     lib.msgw_download_hprop.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp, _dp, _dp, _dp]
+    lib.msgw_snapshot_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.msgw_snapshot_download.argtypes = [C.c_void_p, C.c_void_p] + [_dp] * 9
+    lib.msgw_snapshot_destroy.argtypes = [C.c_void_p, C.c_void_p]
     if lib.msgw_abi_version() != 2:
         raise MsgwError("libmsgwam_hip.so has an unexpected ABI version")
     _lib = lib
@@ -223,16 +227,38 @@ class Propagator:
                                            _p(out)), "msgw_saturation")
         return out
 
-    def download_rays(self):
-        dens, rr, mm = np.empty(self.n), np.empty(self.n), np.empty(self.n)
-        self._chk(self.lib.msgw_download_rays(self.ctx, self.n, _p(dens), _p(rr), _p(mm)), "msgw_download_rays")
-        return dens, rr, mm
+    def download_rays(self, which=("dens", "rr", "mm")):
+        """The evolving per-ray slots (blocking); `which` selects a subset, returned in that order."""
+        out = {k: np.empty(self.n) for k in which}
+        self._chk(self.lib.msgw_download_rays(self.ctx, self.n, _p(out.get("dens")), _p(out.get("rr")),
+                                              _p(out.get("mm"))), "msgw_download_rays")
+        return tuple(out[k] for k in which)
 
-    def download_column(self):
+    def download_column(self, which=("uu", "vv")):
         nc = self.ngrid - 1
-        uu, vv = np.empty(nc), np.empty(nc)
-        self._chk(self.lib.msgw_download_column(self.ctx, _p(uu), _p(vv)), "msgw_download_column")
-        return uu, vv
+        out = {k: np.empty(nc) for k in which}
+        self._chk(self.lib.msgw_download_column(self.ctx, _p(out.get("uu")), _p(out.get("vv"))), "msgw_download_column")
+        return tuple(out[k] for k in which)
+
+    # -- snapshots (lazy host copies) ------------------------------------------
+    _SNAP_SLOTS = ("dens", "rr", "mm", "uu", "vv", "lam", "phi", "kk", "ll")
+
+    def snapshot(self):
+        """Stream-ordered device copy of the evolving slots; returns an opaque handle (release with snapshot_free)."""
+        h = C.c_void_p()
+        self._chk(self.lib.msgw_snapshot_create(self.ctx, C.byref(h)), "msgw_snapshot_create")
+        return (h, self.n)
+
+    def snapshot_download(self, snap, name):
+        h, n = snap
+        out = np.empty(self.ngrid - 1 if name in ("uu", "vv") else n)
+        args = [_p(out) if k == name else None for k in self._SNAP_SLOTS]
+        self._chk(self.lib.msgw_snapshot_download(self.ctx, h, *args), "msgw_snapshot_download")
+        return out
+
+    def snapshot_free(self, snap):
+        if getattr(self, "ctx", None):
+            self.lib.msgw_snapshot_destroy(self.ctx, snap[0])
 
     def sync(self):
         self._chk(self.lib.msgw_sync(self.ctx), "msgw_sync")

@@ -12,20 +12,26 @@ setters; `omega`; and the hot-path entry points `RK3`, `rhs_default`,
 `saturation`, `wave_projection`, which run on the GPU.  There is NO CPU
 fallback for those four: without the HIP library or a GPU they raise.
 
-Scope and deliberate differences (also in DESIGN.md):
-  * Only a scalar `bvf` is implemented.  Both `HPROP_GLOBAL` branches run on the GPU:
-    False (the driver's, raytracer.py:38) through the tuned kernels, True (lam, phi,
-    kk, ll evolve as well) through a plain kernel of its own.
-  * `model_config['rhs']` must be one of this module's built-ins (`rhs_default`,
-    `rhs_fixed_background`).  An arbitrary Python callable is opaque host code
-    that cannot run on the device; it raises TypeError instead of silently
-    running a CPU path.
-  * `RK3` builds its 11-slot object array slot by slot, so `nray == ngrid-1`
-    works (the reference crashes there, lib/libprop.py:668-674).
+Scope and deliberate differences (also in DESIGN.md, INTEGRATION.md):
+  * Only a scalar `bvf` is implemented.  Both `HPROP_GLOBAL` branches run on the GPU: False (the driver's,
+    raytracer.py:38) through the tuned kernels, True (lam, phi, kk, ll evolve as well) through a plain kernel of
+    its own.
+  * `model_config['rhs']` is honoured as in the reference (lib/libprop.py:691).  With the built-ins `rhs_default` /
+    `rhs_fixed_background` a whole `RK3` step is one GPU call; any other callable (e.g. a hook around
+    `lprop.rhs_default`) is driven by the reference's six RK lines on the host, its `rhs_default` calls on the GPU.
+  * The evolving slots of the state `RK3` returns are `DeviceArray` objects: float64 arrays that live in HBM and are
+    copied to the host on first access, so a loop that feeds the state back never crosses PCIe
+    (`set_lazy_download(False)` returns plain ndarrays).  The unchanged slots are the caller's own objects.
+    A slot counts as resident only if it is the same object as last time AND its content fingerprint is unchanged
+    (`set_residency`), so an in-place edit between two calls is uploaded, as the reference would see it.
+  * `RK3` builds its 11-slot object array slot by slot, so `nray == ngrid-1` works (the reference crashes there,
+    lib/libprop.py:668-674).
 Column/initial-condition helpers (`set_hydrostatics`, `set_pressure_gradient`,
 `velocities_*`, `omega`) are one-off O(ngrid)/O(nray) host-side setup in numpy,
 as in the reference.
 """
+import weakref
+
 import numpy as np
 
 from . import _capi
@@ -209,37 +215,218 @@ def velocities_tanh(lam, phi, rr):
 # ----------------------------------------------------------------------------
 # device backend
 # ----------------------------------------------------------------------------
+try:                                                     # content digests of host arrays (residency checks)
+    import xxhash as _xxhash
+
+    def _digest(a):
+        a = np.ascontiguousarray(a)
+        return (a.shape, a.dtype.str, _xxhash.xxh3_64_intdigest(memoryview(a).cast("B")))
+except ImportError:                                      # numpy only: wrap-around sum and xor of the 64-bit words
+    def _digest(a):
+        a = np.ascontiguousarray(a)
+        w = a.view(np.uint64) if a.dtype.itemsize == 8 and a.size else np.frombuffer(a.tobytes(), dtype=np.uint8)
+        return (a.shape, a.dtype.str, int(np.add.reduce(w, dtype=np.uint64)), int(np.bitwise_xor.reduce(w)) if w.size else 0)
+
+
+def _sampled(a):
+    """Cheap fingerprint: buffer address, shape and ~4k strided samples + both ends (residency mode 'fast')."""
+    a = np.asarray(a)
+    f = a.reshape(-1)
+    step = max(1, f.size // 4096)
+    return (a.__array_interface__["data"][0], a.shape, a.dtype.str, f[::step].tobytes(), f[:64].tobytes(), f[-64:].tobytes())
+
+
+class _Snapshot:
+    """Device copy of a past state, shared by the DeviceArrays of that generation; freed with the last of them."""
+
+    def __init__(self, prop, users):
+        self.prop = prop
+        self.handle = prop.snapshot()
+        self.users = [weakref.ref(a) for a in users]
+
+    def fetch(self, name):
+        return self.prop.snapshot_download(self.handle, name)
+
+    def materialize_users(self):
+        """Before the context goes away: copy what is still unread to the host."""
+        for w in self.users:
+            a = w()
+            if a is not None and a._host is None and a._snap is self:
+                a._get()
+
+    def __del__(self):
+        try:
+            if self.handle is not None:
+                self.prop.snapshot_free(self.handle)
+        except Exception:
+            pass
+
+
+class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
+    """An evolving slot of the state `RK3` returns (dens, rr, mm, uu, vv; lam, phi, kk, ll with HPROP on).
+
+    It stands for a float64 array that lives in HBM and is copied to the host on first access (indexing, arithmetic,
+    `np.asarray`, assignment into another array ...).  A loop that only feeds the state back into `RK3` never copies
+    anything; a state that is advanced before it was read stays readable (the library keeps a device snapshot of it
+    as long as one of its DeviceArrays is alive).  `lprop.set_lazy_download(False)` makes `RK3` return plain ndarrays.
+    """
+    __array_priority__ = 1000
+
+    def __init__(self, backend, name, shape, gen):
+        self._backend, self._name, self._shape, self._gen = backend, name, tuple(shape), gen
+        self._kind = "col" if name in ("uu", "vv") else "rays"
+        self._host = None                                   # the materialised ndarray
+        self._mark = None                                   # its digest at download (detects in-place edits)
+        self._snap = None                                   # _Snapshot once the device has moved on
+
+    # -- materialisation -----------------------------------------------------
+    def _get(self):
+        if self._host is None:
+            self._host = self._backend.fetch(self)
+            self._mark = _digest(self._host)
+            self._snap = None
+        return self._host
+
+    def _pristine(self):
+        """True when the values on the device are still what this object shows to the caller."""
+        return self._host is None or _digest(self._host) == self._mark
+
+    # -- ndarray protocol ------------------------------------------------------
+    def __array__(self, dtype=None, copy=None):
+        a = self._get()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        conv = lambda x: x._get() if isinstance(x, DeviceArray) else x
+        if "out" in kwargs:
+            kwargs["out"] = tuple(conv(x) for x in kwargs["out"])
+        return getattr(ufunc, method)(*[conv(x) for x in inputs], **kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        if func in (np.shape, np.ndim, np.size) and len(args) == 1 and not kwargs:   # metadata: nothing to copy
+            return {np.shape: self.shape, np.ndim: self.ndim, np.size: self.size}[func]
+        def conv(x):
+            if isinstance(x, DeviceArray):
+                return x._get()
+            if isinstance(x, (list, tuple)):
+                return type(x)(conv(y) for y in x)
+            return x
+        return func(*[conv(x) for x in args], **{k: conv(v) for k, v in kwargs.items()})
+
+    shape = property(lambda self: self._shape)
+    dtype = property(lambda self: np.dtype(np.float64))
+    ndim = property(lambda self: len(self._shape))
+    size = property(lambda self: int(np.prod(self._shape)))
+
+    def __len__(self):
+        return self._shape[0]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __setitem__(self, k, v):
+        self._get()[k] = v
+
+    def __getattr__(self, name):                            # everything else: the ndarray's own attribute
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._get(), name)
+
+    def __repr__(self):
+        return repr(self._get()) if self._host is not None else f"DeviceArray({self._name}, shape={self._shape}, on device)"
+
+
+_EVOLVING = {0: "dens", 3: "rr", 7: "mm", 9: "uu", 10: "vv"}
+_EVOLVING_HPROP = {1: "lam", 2: "phi", 5: "kk", 6: "ll"}
+
+
 class _Backend:
     """One lazily created GPU context + what is resident in it."""
 
     def __init__(self):
         self.prop = None
         self.device = 0
-        self.cfg = None         # (bvf, phi0, kappa, saturate_online)
+        self.cfg = None         # (bvf, phi0, kappa, saturate_online, hprop)
         self.col = None         # copies of grid, grids, rhobar, pressure_gradient
-        self.col_uv = None      # the (uu, vv) OBJECTS that are resident
-        self.rays = None        # dict: input objects resident + statics objects
-        self.out = None         # the arrays returned by the last RK3
+        self.rays = None        # what the device's ray state corresponds to: {slot: key}, see _slot_key
+        self.col_uv = None      # the same for the wind columns: (key_uu, key_vv)
+        self.gen = {"rays": 0, "col": 0}   # generations of the resident ray state / wind columns (advanced by
+                                           # every RK3 and every upload)
+        self.live = []          # weak references to the DeviceArrays of the current generations
+        self.snaps = []         # weak references to the device snapshots of older generations
 
     def context(self, ngrid, nray):
         p = self.prop
         if p is None or p.ngrid != ngrid or nray > p.cap:
-            if p is not None:
-                p.close()
             cap = max(int(nray), 1024)
             if p is not None and p.ngrid == ngrid:
                 cap = max(cap, 2 * p.cap)
+            if p is not None:
+                self.reset(keep_device=True)
             self.prop = _capi.Propagator(ngrid, cap, device=self.device)
-            self.cfg = self.col = self.col_uv = self.rays = self.out = None
         return self.prop
 
-    def reset(self):
+    def invalidate(self):
+        """Forget what is resident (after an error, or when the context goes away): the next call uploads."""
+        self.cfg = self.col = self.rays = self.col_uv = None
+        self.gen = {k: v + 1 for k, v in self.gen.items()}
+
+    def materialize_live(self):
+        """Copy the not yet read results of the current generation to the host (before the device state is
+        overwritten by an upload, or the context is closed)."""
+        for w in self.live:
+            a = w()
+            if a is not None and a._host is None:
+                a._get()
+        self.live = []
+
+    def protect_live(self):
+        """Before the device state advances: results of the current generation that nobody has read yet stay
+        readable through ONE device snapshot shared by them (freed when the last of them dies or is read)."""
+        alive = [a for a in (w() for w in self.live) if a is not None and a._host is None and a._snap is None]
+        if alive:
+            snap = _Snapshot(self.prop, alive)
+            for a in alive:
+                a._snap = snap
+            self.snaps = [w for w in self.snaps if w() is not None] + [weakref.ref(snap)]
+        self.live = []
+
+    def fetch(self, a):
+        if a._snap is not None:
+            return a._snap.fetch(a._name)
+        if a._gen != self.gen[a._kind] or self.prop is None:
+            raise RuntimeError("this state is no longer on the device (the GPU context was released)")
+        p = self.prop
+        if a._name in ("dens", "rr", "mm"):
+            return p.download_rays((a._name,))[0]
+        if a._name in ("uu", "vv"):
+            return p.download_column((a._name,))[0]
+        return dict(zip(("lam", "phi", "kk", "ll"), p.download_hprop()))[a._name]
+
+    def reset(self, keep_device=False):
         if self.prop is not None:
+            try:
+                self.materialize_live()
+                for w in self.snaps:
+                    if w() is not None:
+                        w().materialize_users()
+            except Exception:
+                pass
             self.prop.close()
+        dev = self.device
         self.__init__()
+        if keep_device:
+            self.device = dev
 
 
 _backend = _Backend()
+_lazy = True
+_residency = "safe"
 
 
 def set_device(device):
@@ -249,10 +436,30 @@ def set_device(device):
 
 
 def release_device():
-    """Free the GPU context (the next hot-path call recreates it)."""
-    dev = _backend.device
-    _backend.reset()
-    _backend.device = dev
+    """Free the GPU context (the next hot-path call recreates it).  Results that were not read yet are copied to
+    the host first."""
+    _backend.reset(keep_device=True)
+
+
+def set_lazy_download(on=True):
+    """True (default): `RK3` returns its evolving slots as DeviceArray objects that are copied to the host on first
+    access.  False: plain float64 ndarrays, copied eagerly, exactly the reference's return types."""
+    global _lazy
+    _lazy = bool(on)
+
+
+def set_residency(mode="safe"):
+    """How `RK3` / `rhs_default` decide that a slot the caller passes is already on the device:
+      'safe' (default)  the same object as last time AND an unchanged content digest (an in-place edit is seen and
+                        uploaded; costs one pass over the frozen slots per call, ~0.4 ms per 1e6 rays and slot);
+      'fast'            the same object and a strided sample of ~4k values (an edit of a few rays can go unnoticed);
+      'off'             nothing is assumed resident: every call uploads every slot (the reference's semantics at
+                        the reference's cost model)."""
+    global _residency
+    if mode not in ("safe", "fast", "off"):
+        raise ValueError("residency mode must be 'safe', 'fast' or 'off'")
+    _residency = mode
+    _backend.rays = _backend.col_uv = None
 
 
 def _check_scope():
@@ -266,10 +473,32 @@ def _same(a, b):
     return a is b or (a is not None and b is not None and np.array_equal(a, b))
 
 
+def _slot_key(x):
+    """What is remembered about an array that was uploaded / returned, to recognise it next time (weakly: the
+    caller's arrays are not kept alive)."""
+    if isinstance(x, DeviceArray):
+        return ("dev", weakref.ref(x))
+    if _residency == "off" or not isinstance(x, np.ndarray):
+        return None                                          # lists, scalars ...: converted anew on every call
+    return ("host", weakref.ref(x), _digest(x) if _residency == "safe" else _sampled(x))
+
+
+def _slot_resident(x, key):
+    """Is `x` what the device holds for this slot?  The same object as last time and, for host arrays, an unchanged
+    content fingerprint (an in-place edit must be uploaded); for a DeviceArray: still of the current generation and
+    not edited since it was read."""
+    if key is None or _residency == "off" or x is not key[1]():
+        return False
+    if key[0] == "dev":
+        return x._gen == _backend.gen[x._kind] and x._pristine()
+    return (_digest(x) if _residency == "safe" else _sampled(x)) == key[2]
+
+
 def _sync_config_and_column(p, uu, vv, force_uv):
     cfg = (float(model_config['bvf']), float(model_config['phi0']), float(model_config['kappa']),
            bool(model_config['saturate_online']), bool(HPROP_GLOBAL))
     if _backend.cfg != cfg:
+        _backend.materialize_live()
         p.set_config(cfg[0], cfg[1], cfg[2], cfg[3], hprop=cfg[4])
         _backend.cfg = cfg
         _backend.rays = None                                     # lam, phi must be (re)uploaded with the rays
@@ -280,29 +509,53 @@ def _sync_config_and_column(p, uu, vv, force_uv):
         raise RuntimeError("lprop.pressure_gradient is not set: call set_pressure_gradient(uu, vv) "
                            "(raytracer.py:99)")
     stale = col is None or any(not _same(a, b) for a, b in zip(col, new))
-    uv_resident = (not force_uv and not stale and _backend.col_uv is not None
-                   and _backend.col_uv[0] is uu and _backend.col_uv[1] is vv)
+    keys = _backend.col_uv
+    uv_resident = (not force_uv and not stale and keys is not None
+                   and _slot_resident(uu, keys[0]) and _slot_resident(vv, keys[1]))
     if not uv_resident:
-        p.set_column(new[0], new[1], new[2], new[3], uu, vv)
+        _backend.materialize_live()                              # the upload overwrites what they stand for
+        p.set_column(new[0], new[1], new[2], new[3], np.asarray(uu, dtype=np.float64), np.asarray(vv, dtype=np.float64))
         _backend.col = tuple(a.copy() for a in new)
-        _backend.col_uv = (uu, vv)
+        _backend.gen["col"] += 1
+        for a in (uu, vv):                                       # results of an earlier call, uploaded again as they are
+            if isinstance(a, DeviceArray):
+                a._gen = _backend.gen["col"]
+        _backend.col_uv = (_slot_key(uu), _slot_key(vv))
 
 
 _RAY_SLOTS = (0, 3, 4, 5, 6, 7, 8, 2)      # dens rr drr kk ll mm dmm phi
+_STATICS = ('dkk', 'dll', 'rr_mm_area')
 
 
 def _sync_rays(p, var):
-    st = (statics['dkk'], statics['dll'], statics['rr_mm_area'])     # KeyError as in :585-587
+    st = [statics[k] for k in _STATICS]                              # KeyError as in :585-587
     res = _backend.rays
     slots = _RAY_SLOTS + ((1,) if HPROP_GLOBAL else ())          # lam matters only with horizontal propagation
-    resident = (res is not None and all(res['in'][i] is var[i] for i in slots)
-                and all(a is b for a, b in zip(res['st'], st)))
+    resident = (res is not None and all(_slot_resident(var[i], res.get(i)) for i in slots)
+                and all(_slot_resident(a, res.get(k)) for a, k in zip(st, _STATICS)))
     if not resident:
+        _backend.materialize_live()                              # the upload overwrites what they stand for
         dens, lam, phi, rr, drr, kk, ll, mm, dmm = [np.asarray(var[i], dtype=np.float64) for i in range(9)]
         p.upload_rays(dens, rr, drr, kk, ll, mm, dmm, phi, st[0], st[1], st[2])
         if HPROP_GLOBAL:
             p.upload_hprop(lam, phi)
+        _backend.gen["rays"] += 1
+        for i in slots:                                          # results of an earlier call, uploaded again as they are
+            if isinstance(var[i], DeviceArray):
+                var[i]._gen = _backend.gen["rays"]
+        _backend.rays = {i: _slot_key(var[i]) for i in slots}
+        _backend.rays.update({k: _slot_key(a) for a, k in zip(st, _STATICS)})
     return not resident
+
+
+def _sync_config_only(p):
+    cfg = (float(model_config['bvf']), float(model_config['phi0']), float(model_config['kappa']),
+           bool(model_config['saturate_online']), bool(HPROP_GLOBAL))
+    if _backend.cfg != cfg:
+        _backend.materialize_live()
+        p.set_config(cfg[0], cfg[1], cfg[2], cfg[3], hprop=cfg[4])
+        _backend.cfg = cfg
+        _backend.rays = None
 
 
 def _prepare(var):
@@ -323,14 +576,17 @@ def _pack(slots):
     return out
 
 
-def _flags_for(rhs):
-    if rhs is rhs_default:
-        return 0
-    if rhs is rhs_fixed_background:
-        return _capi.FIXED_BACKGROUND
-    raise TypeError(
-        "model_config['rhs'] must be msgwam_amd.libprop.rhs_default or .rhs_fixed_background; an "
-        "arbitrary Python callable cannot run on the GPU and there is no CPU fallback")
+def _guard(fn):
+    """Any error of the HIP library leaves the device state unknown: forget what was resident, so that the next call
+    uploads again (and, after a time-out of the persistent kernel, proceeds on the per-stage kernels)."""
+    def wrapped(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except _capi.MsgwError:
+            _backend.invalidate()
+            raise
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
 
 
 # ----------------------------------------------------------------------------
@@ -351,11 +607,10 @@ def rhs_fixed_background(dt, var_in):
     return _rhs(dt, var_in, _capi.FIXED_BACKGROUND)
 
 
+@_guard
 def _rhs(dt, var_in, flags):
     p = _prepare(var_in)
     t = p.rhs(dt, flags)
-    _backend.rays = dict(**{'in': list(var_in)}, st=(statics['dkk'], statics['dll'], statics['rr_mm_area']))
-    _backend.col_uv = (var_in[9], var_in[10])
     z = lambda: np.zeros(np.shape(var_in[5]))
     if HPROP_GLOBAL:                                             # lam, phi, kk, ll have tendencies too (:638-643)
         lam, phi, kk, ll = p.download_hprop(tendencies=True)
@@ -364,23 +619,68 @@ def _rhs(dt, var_in, flags):
 
 
 def RK3(dt, var):
-    """lib/libprop.py:680-700 on the GPU: one low-storage RK3 step of the full
-    state (rays AND mean flow: uu, vv advance at every stage).  The state stays
-    resident between calls when the caller passes back the arrays it was given."""
-    flags = _flags_for(model_config['rhs'])
+    """lib/libprop.py:680-700: one low-storage RK3 step of the full state (rays AND mean flow: uu, vv advance at
+    every stage).
+
+    `model_config['rhs']` is honoured as in the reference (:691).  With one of this module's built-ins
+    (`rhs_default`, `rhs_fixed_background`) the whole step runs on the GPU and the state stays resident between
+    calls when the caller passes back what it was given.  Any other callable -- e.g. a hook that post-processes
+    `lprop.rhs_default(dt, var)` -- is called three times per step by the reference's own six RK lines (:693-698)
+    evaluated here on the host; the hook's calls of `rhs_default` still run on the GPU."""
+    rhs_ = model_config['rhs']
+    if rhs_ is rhs_default:
+        return _rk3_device(dt, var, 0)
+    if rhs_ is rhs_fixed_background:
+        return _rk3_device(dt, var, _capi.FIXED_BACKGROUND)
+    if not callable(rhs_):
+        raise TypeError("model_config['rhs'] must be callable: rhs(dt, var_in) -> 11 tendencies (lib/libprop.py:691)")
+    var = _pack([np.asarray(a, dtype=np.float64) for a in var])     # object array of 11 float64 arrays, slot by slot
+    qq = dt * _as_state(rhs_(dt, var))                               # :693
+    var = var + qq / 3                                               # :694
+    qq = dt * _as_state(rhs_(dt, var)) - 5 / 9 * qq                  # :695
+    var = var + 15 / 16 * qq                                         # :696
+    qq = dt * _as_state(rhs_(dt, var)) - 153 / 128 * qq              # :697
+    var = var + 8 / 15 * qq                                          # :698
+    return var
+
+
+def _as_state(t):
+    """The 11 tendencies a user hook returned, as an object array of float64 arrays."""
+    if len(t) != 11:
+        raise ValueError("the rhs hook must return 11 tendencies (lib/libprop.py:668-674)")
+    return _pack([np.asarray(a, dtype=np.float64) for a in t])
+
+
+@_guard
+def _rk3_device(dt, var, flags):
     p = _prepare(var)
+    _backend.protect_live()                                      # unread results of the state that is about to move
     p.step(dt, 1, flags | _capi.NO_GRAPH)
-    dens, rr, mm = p.download_rays()
-    uu, vv = p.download_column()
+    moved = dict(_EVOLVING)                                      # slots whose device values have just changed
     if HPROP_GLOBAL:
-        lam, phi, kk, ll = p.download_hprop()
-    else:
-        lam, phi, kk, ll = (np.array(var[i], dtype=np.float64) for i in (1, 2, 5, 6))
-    out = [dens, lam, phi, rr, np.array(var[4], dtype=np.float64), kk, ll, mm,
-           np.array(var[8], dtype=np.float64), uu, vv]
-    # what is now on the device corresponds to `out`; frozen slots are equal by value
-    _backend.rays = dict(**{'in': list(out)}, st=(statics['dkk'], statics['dll'], statics['rr_mm_area']))
-    _backend.col_uv = (uu, vv)
+        moved.update(_EVOLVING_HPROP)
+    if flags & _capi.FIXED_BACKGROUND:                           # the hook zeroes the tendencies of slots 9, 10
+        moved.pop(9), moved.pop(10)
+    _backend.gen["rays"] += 1
+    if 9 in moved:
+        _backend.gen["col"] += 1
+    out = []
+    for i in range(11):
+        if i in moved:
+            out.append(DeviceArray(_backend, moved[i], np.shape(var[i]), _backend.gen["col" if i >= 9 else "rays"]))
+        else:                                                    # unchanged: the caller's own object goes back
+            out.append(var[i])
+            if isinstance(var[i], DeviceArray):                  # (a result of an earlier call: still current)
+                var[i]._gen = _backend.gen[var[i]._kind]
+    if not _lazy:                                                # plain ndarrays, copied now
+        out = [a._get() if isinstance(a, DeviceArray) and i in moved else a for i, a in enumerate(out)]
+    _backend.live = [weakref.ref(a) for a in out if isinstance(a, DeviceArray) and a._host is None]
+    # what is on the device now corresponds to `out`
+    for i in moved:
+        if i < 9:
+            _backend.rays[i] = _slot_key(out[i])
+    if 9 in moved:
+        _backend.col_uv = (_slot_key(out[9]), _slot_key(out[10]))
     return _pack(out)
 
 
@@ -391,9 +691,11 @@ def saturation(dt, dens, rr_center, rr_center_st, drr, drr_st, kk, ll, mm_center
     _check_scope()
     n = len(dens)
     p = _backend.context(len(grid), n)
-    # the column may not be resident yet when the caller never ran RK3
-    uv = _backend.col_uv or (np.zeros(len(grids)), np.zeros(len(grids)))
-    _sync_config_and_column(p, uv[0], uv[1], force_uv=False)
+    if _backend.col is None:                                     # the caller never ran RK3: any wind column will do,
+        z = np.zeros(len(grids))                                 # saturation only reads grids and rhobar
+        _sync_config_and_column(p, z, z, force_uv=True)
+    else:
+        _sync_config_only(p)
     return p.saturation(dt, direct, dens, rr_center, rr_center_st, drr, drr_st, kk, ll, mm_center,
                         mm_center_st, statics['dkk'], statics['dll'], statics['rr_mm_area'])
 

@@ -33,11 +33,13 @@ def _check(got, d, prefix, tol=1e-10):
     scale = max(np.max(np.abs(d[f"{prefix}_uu"])), np.max(np.abs(d[f"{prefix}_vv"])), 1e-300)
     for i, k in enumerate(STATE_KEYS):
         want = d[f"{prefix}_{k}"]
-        assert isinstance(got[i], np.ndarray) and got[i].dtype == np.float64 and got[i].shape == want.shape
+        assert got[i].dtype == np.float64 and got[i].shape == want.shape and len(got[i]) == len(want)
+        g = np.asarray(got[i])                             # (evolving slots may be DeviceArrays: copied here)
+        assert isinstance(g, np.ndarray) and g.dtype == np.float64
         if k in ("uu", "vv"):
-            assert np.max(np.abs(got[i] - want)) / scale <= tol, k
+            assert np.max(np.abs(g - want)) / scale <= tol, k
         else:
-            assert relerr(got[i], want) <= tol, (k, relerr(got[i], want))
+            assert relerr(g, want) <= tol, (k, relerr(g, want))
 
 
 def test_rk3_and_rhs_default_match_reference():
@@ -91,8 +93,11 @@ def test_scope_errors_are_loud():
     d = load("g3_rk3_coupled_driver")
     _configure_from(d, lprop)
     st = _obj(state_from(d, "in"))
-    lprop.set_model_setup(rhs=lambda dt, v: v)
+    lprop.set_model_setup(rhs="not callable")
     with pytest.raises(TypeError):
+        lprop.RK3(120.0, st)
+    lprop.set_model_setup(rhs=lambda dt, v: v[:3])           # a hook must return 11 tendencies
+    with pytest.raises(ValueError):
         lprop.RK3(120.0, st)
     lprop.set_model_setup(rhs=lprop.rhs_default)
     with pytest.raises(ValueError):
@@ -148,4 +153,112 @@ def test_hprop_global_true_through_the_module_surface():
             assert np.all(np.abs(t[i] - want) <= 1e-10 * np.abs(want) + 1e-12 * scale), k
     finally:
         lprop.HPROP_GLOBAL = False
+        lprop.release_device()
+
+
+def test_rhs_hook_around_rhs_default_is_config1():
+    """The reference's own way to freeze the mean flow: a user hook that zeroes slots 9, 10 of
+    rhs_default's result.  The hook is opaque Python, so the six RK lines (lib/libprop.py:693-698) run on the host;
+    its rhs_default calls run on the GPU.  Against the reference's rows of config 1."""
+    import msgwam_amd.libprop as lprop
+    d = load("g3_rk3_fixedbg_config1")
+    _configure_from(d, lprop)
+    calls = []
+
+    def frozen_background(dt, var):
+        t = lprop.rhs_default(dt, var)
+        calls.append(1)
+        t[9], t[10] = np.zeros_like(t[9]), np.zeros_like(t[10])
+        return t
+
+    lprop.set_model_setup(rhs=frozen_background)
+    try:
+        out = _obj(state_from(d, "in"))
+        for n in range(1, 11):
+            out = lprop.RK3(float(d["dt"]), out)
+            assert out.dtype == object and out.shape == (11,)
+            if n in (1, 10):
+                _check(out, d, f"s{n}")
+        assert len(calls) == 30                              # three stages per step
+        assert np.array_equal(out[9], d["in_uu"])            # the hook froze the column
+    finally:
+        lprop.set_model_setup(rhs=lprop.rhs_default)
+        lprop.release_device()
+
+
+def test_state_fed_back_stays_on_the_device_and_edits_are_seen(monkeypatch):
+    """Lazy host copies: feeding the returned state back never downloads; an older state stays readable after the
+    device has moved on (device snapshot); an in-place edit between two calls -- of a returned DeviceArray or of a
+    frozen input array -- is uploaded, as the reference (which re-reads every slot on every call) would see it."""
+    import msgwam_amd.libprop as lprop
+    from msgwam_amd import _capi
+    from oracle import msgwam_oracle as orc
+    from helpers import setup_from
+    d = load("g3_rk3_coupled_driver")
+    _configure_from(d, lprop)
+    dt = float(d["dt"])
+    counts = {"rays": 0, "col": 0, "up": 0}
+    for name, key in (("download_rays", "rays"), ("download_column", "col"), ("upload_rays", "up")):
+        orig = getattr(_capi.Propagator, name)
+        monkeypatch.setattr(_capi.Propagator, name,
+                            lambda self, *a, _o=orig, _k=key, **kw: (counts.__setitem__(_k, counts[_k] + 1), _o(self, *a, **kw))[1])
+    try:
+        st = _obj(state_from(d, "in"))
+        s1 = lprop.RK3(dt, st)
+        assert isinstance(s1[3], lprop.DeviceArray) and s1[5] is st[5]     # evolving: on device; frozen: the caller's
+        state = s1
+        for _ in range(9):
+            state = lprop.RK3(dt, state)
+        assert counts == {"rays": 0, "col": 0, "up": 1}      # ten steps: one upload, nothing copied back
+        _check(state, d, "s10")                              # first access: now it is copied
+        assert counts["rays"] == 3 and counts["col"] == 2
+        _check(s1, d, "s1")                                  # the state of nine steps ago, from its device snapshot
+        # (1) edit a returned slot in place, (2) edit a frozen input array in place: both must take effect
+        s = setup_from(d)
+        state[0][7] = 0.0                                    # DeviceArray.__setitem__
+        kk = state[5]
+        kk[11] *= 1.5                                        # the caller's own ndarray
+        want = orc.rk3(s, dt, [np.asarray(a, dtype=np.float64) for a in state])
+        got = lprop.RK3(dt, state)
+        for i, k in enumerate(STATE_KEYS):
+            g = np.asarray(got[i])
+            if k in ("uu", "vv"):
+                assert np.max(np.abs(g - want[i])) <= 1e-10 * np.max(np.abs(want[9])), k
+            else:
+                assert relerr(g, want[i]) <= 1e-10, k
+        assert got[0][7] == 0.0 and counts["up"] == 2
+        # plain ndarrays on request
+        lprop.set_lazy_download(False)
+        out = lprop.RK3(dt, got)
+        assert all(type(a) is np.ndarray for a in out)
+    finally:
+        lprop.set_lazy_download(True)
+        lprop.release_device()
+
+
+def test_library_error_resets_what_is_assumed_resident(monkeypatch):
+    """After an error of the HIP library (e.g. the persistent kernel's time-out) the mirror forgets what it assumed
+    to be resident: the retry uploads again instead of failing forever on a state the library has dropped."""
+    import msgwam_amd.libprop as lprop
+    from msgwam_amd import _capi
+    d = load("g3_rk3_coupled_driver")
+    _configure_from(d, lprop)
+    try:
+        state = lprop.RK3(float(d["dt"]), _obj(state_from(d, "in")))
+        orig = _capi.Propagator.step
+        fail = {"n": 1}
+
+        def flaky(self, *a, **kw):
+            if fail["n"]:
+                fail["n"] -= 1
+                raise _capi.MsgwError("msgw_step: injected failure")
+            return orig(self, *a, **kw)
+
+        monkeypatch.setattr(_capi.Propagator, "step", flaky)
+        with pytest.raises(_capi.MsgwError):
+            lprop.RK3(float(d["dt"]), state)
+        out = lprop.RK3(float(d["dt"]), state)               # uploads `state` again (copied from the device first)
+        _check(out, d, "s2") if "s2_rr" in d else None
+        assert np.all(np.isfinite(np.asarray(out[3])))
+    finally:
         lprop.release_device()

@@ -103,3 +103,85 @@ def test_rhs_building_blocks_match_the_reference():
         assert v.shape == (4, 3, 5) and np.array_equal(v[0, 0], v[0, 2])
     finally:
         lprop.HPROP_GLOBAL = False
+
+
+def test_rk3_drives_a_foreign_rhs_hook_with_the_reference_rk_lines():
+    """model_config['rhs'] may be any callable (lib/libprop.py:691).  A hook that never touches the GPU: linear
+    tendencies, for which the Williamson scheme (lib/libprop.py:693-698) has a closed form."""
+    import msgwam_amd.libprop as lprop
+    rng = np.random.default_rng(3)
+    st = np.empty(11, dtype=object)
+    for i in range(11):
+        st[i] = rng.normal(size=7 if i < 9 else 5)
+    lam = np.linspace(-0.9, 0.4, 11)
+
+    def rhs(dt, var):
+        out = np.empty(11, dtype=object)
+        for i in range(11):
+            out[i] = lam[i] * var[i]
+        return out
+
+    old = lprop.model_config["rhs"]
+    lprop.set_model_setup(rhs=rhs)
+    try:
+        dt = 0.3
+        got = lprop.RK3(dt, st)
+        for i in range(11):
+            q = dt * (lam[i] * st[i]); y = st[i] + q / 3
+            q = dt * (lam[i] * y) - 5 / 9 * q; y = y + 15 / 16 * q
+            q = dt * (lam[i] * y) - 153 / 128 * q; y = y + 8 / 15 * q
+            assert np.array_equal(got[i], y), i
+            z = dt * lam[i]                                  # third-order: 1 + z + z^2/2 + z^3/6
+            assert np.allclose(got[i], st[i] * (1 + z + z * z / 2 + z ** 3 / 6), rtol=1e-13)
+    finally:
+        lprop.set_model_setup(rhs=old)
+
+
+def test_device_array_is_lazy_and_behaves_like_an_ndarray():
+    """DeviceArray against a stub backend (no GPU): nothing is fetched until the values are needed; then it acts as
+    the float64 ndarray it stands for; in-place edits are noticed."""
+    import msgwam_amd.libprop as lprop
+
+    class Stub:
+        def __init__(self):
+            self.fetched = 0
+
+        def fetch(self, a):
+            self.fetched += 1
+            return np.arange(6, dtype=np.float64)
+
+    b = Stub()
+    a = lprop.DeviceArray(b, "rr", (6,), 0)
+    assert a.shape == (6,) and len(a) == 6 and a.dtype == np.float64 and a.ndim == 1 and a.size == 6
+    assert np.shape(a) == (6,) and "on device" in repr(a) and b.fetched == 0
+    assert a._pristine()
+    assert np.array_equal(a + 1, np.arange(1, 7)) and b.fetched == 1
+    assert np.array_equal(np.asarray(a), np.arange(6)) and a[2] == 2.0 and float(np.sum(a)) == 15.0
+    assert np.array_equal(np.concatenate([a, a]), np.tile(np.arange(6.0), 2)) and a.mean() == 2.5
+    hist = np.zeros((2, 6))
+    hist[1] = a                                              # the driver's `int_rr[nt] = state_out[3]`
+    assert np.array_equal(hist[1], np.arange(6)) and b.fetched == 1
+    assert a._pristine()
+    a[3] = -1.0
+    assert not a._pristine() and np.asarray(a)[3] == -1.0
+
+
+def test_residency_fingerprints_see_in_place_edits():
+    import msgwam_amd.libprop as lprop
+    a = np.linspace(0, 1, 100_000)
+    for mode in ("safe", "fast"):
+        lprop.set_residency(mode)
+        key = lprop._slot_key(a)
+        assert lprop._slot_resident(a, key)
+        assert not lprop._slot_resident(a.copy(), key)       # another object: not what was uploaded
+        a[0] += 1.0                                          # both modes see an edit at the ends
+        assert not lprop._slot_resident(a, key)
+        a[0] -= 1.0
+        assert lprop._slot_resident(a, key)
+    lprop.set_residency("safe")
+    key = lprop._slot_key(a)
+    a[12_345] = 7.0                                          # one ray in the middle: the full digest sees it
+    assert not lprop._slot_resident(a, key)
+    lprop.set_residency("off")
+    assert lprop._slot_key(a) is None and not lprop._slot_resident(a, key)
+    lprop.set_residency("safe")
