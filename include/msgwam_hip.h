@@ -94,6 +94,16 @@ int msgw_upload_hprop(msgw_ctx *ctx, int64_t n, const double *lam, const double 
 /* HPROP on: lam, phi, kk, ll (any pointer may be NULL); tendencies != 0: their tendencies left by msgw_rhs. */
 int msgw_download_hprop(msgw_ctx *ctx, int64_t n, int tendencies, double *lam, double *phi, double *kk, double *ll);
 
+/* EXTENSION (the reference has a scalar bvf only, lib/libprop.py:380, :398, :422, :583): buoyancy
+ * frequency as a column bvf[ngrid-1] on lprop.grids, np.interp'ed to the height each expression is about (definition: DESIGN.md 6d).  The vertical group velocity then differs at rr +- drr/2
+ * (lib/libprop.py:635-636), so drr and dmm evolve as well (:641, :645).  Call BEFORE msgw_upload_rays; NULL returns
+ * to the scalar of msgw_set_config.  float64 contexts, HPROP off; steps run in a per-stage kernel of their own.
+ * In the limit N(z) = const the results are the reference's. */
+int msgw_set_bvf_column(msgw_ctx *ctx, const double *bvf);
+/* Slots 4, 8 (drr, dmm) of the resident rays -- they only change with an N(z) column -- or, tendencies != 0, their
+ * tendencies left by msgw_rhs.  Any pointer may be NULL. */
+int msgw_download_extents(msgw_ctx *ctx, int64_t n, int tendencies, double *drr, double *dmm);
+
 /* EXTENSION: the "broken ray" fraction of MSGW_RELAUNCH (default 1e-6; 0 disables that criterion). */
 int msgw_set_relaunch(msgw_ctx *ctx, double frac);
 
@@ -187,13 +197,24 @@ int msgw_download_column(msgw_ctx *ctx, double *uu, double *vv);
 
 /* Snapshots (no reference counterpart; serve the lazy host copies of the Python mirror): a
  * stream-ordered device copy of the evolving slots -- dens, rr, mm, the uu, vv columns and, with HPROP on, lam, phi,
- * kk, ll.  msgw_step does not wait for its kernels, so a caller that may never look at a state need not copy it to
+ * kk, ll and, with an N(z) column, drr, dmm.  msgw_step does not wait for its kernels, so a caller that may never look at a state need not copy it to
  * the host; if it does look later, after the resident state has moved on, the snapshot still has it.
  * Download: any pointer may be NULL.  A snapshot must be destroyed before its context. */
 typedef struct msgw_snapshot msgw_snapshot;
+#define MSGW_SLOT_DENS 0
+#define MSGW_SLOT_RR   1
+#define MSGW_SLOT_MM   2
+#define MSGW_SLOT_UU   3
+#define MSGW_SLOT_VV   4
+#define MSGW_SLOT_LAM  5   /* 5..8: HPROP on */
+#define MSGW_SLOT_PHI  6
+#define MSGW_SLOT_KK   7
+#define MSGW_SLOT_LL   8
+#define MSGW_SLOT_DRR  9   /* 9, 10: N(z) column */
+#define MSGW_SLOT_DMM  10
+#define MSGW_SLOT_COUNT 11
 int msgw_snapshot_create(msgw_ctx *ctx, msgw_snapshot **out);
-int msgw_snapshot_download(msgw_ctx *ctx, msgw_snapshot *snap, double *dens, double *rr, double *mm,
-                           double *uu, double *vv, double *lam, double *phi, double *kk, double *ll);
+int msgw_snapshot_download(msgw_ctx *ctx, msgw_snapshot *snap, int slot, double *out);
 int msgw_snapshot_destroy(msgw_ctx *ctx, msgw_snapshot *snap);
 
 /* Wait for all queued work of this context. */

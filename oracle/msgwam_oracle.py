@@ -93,6 +93,41 @@ def cg_rr(kk, ll, mm, phi, bvf):
 
 
 # --------------------------------------------------------------------------
+# EXTENSION (north_star "U(z)/N2(z) column"): buoyancy frequency as a COLUMN on `grids`.
+# The reference has a scalar `bvf` only (lib/libprop.py:380, :398, :422, :583), so this is build-defined and its
+# parity is UNPINNED, except in the limit N(z) = const, where every expression below reduces to the reference's
+# and the results must be bit-identical (tests/test_oracle_golden.py).  Definition: wherever the reference reads
+# model_config['bvf'], N is np.interp'ed from the column to the height that expression is about --
+#   cg_rr(..., rr +- drr/2)  (:635-636)         N at rr +- drr/2   => ddrr_st = cgr_up - cgr_down != 0 (:641), and
+#                                               drr, dmm evolve (ddmm_st = dmm / drr * ddrr_st, :645)
+#   cg_rr in wave_projection (:139-144)         N at the ray centre .5 * (rr_low + rr_up)
+#   omega(kk, ll, mm_center, phi0) (:597)       N at rr_center;   NN**2 of the cap (:601): N at rr_final
+# -- and dm/dt gets the refraction term of the WKB ray equations that a height-dependent N requires,
+#   dm/dt -= (d omega / d N) * dN/dz = N * (k**2 + l**2) / (omega * |k|**2) * dN/dz   at the ray centre,
+# with dN/dz the derivative of that very interpolant (the slope of the np.interp segment the ray centre is in, 0
+# outside [grids[0], grids[-1]] where np.interp clamps), so that the intrinsic frequency is conserved along a ray in a
+# steady N(z) up to the time-stepping error (the KAT of the tests).  NOTE the reference's ddmm_st = dmm / drr * ddrr_st
+# (:645) keeps dmm / drr constant, not the area drr * dmm; it is reproduced as written.
+# --------------------------------------------------------------------------
+def bvf_at(setup, z):
+    """N at height z: the scalar itself (reference), or np.interp on `grids` (end-value clamping)."""
+    b = setup.bvf
+    return b if np.ndim(b) == 0 else np.interp(z, setup.grids, np.asarray(b, dtype=np.float64))
+
+
+def bvf_gradient_at(setup, z):
+    """dN/dz at height z for a column N: the slope of the np.interp segment grids[j] <= z < grids[j+1] (numpy's own
+    slope expression), 0 where np.interp clamps (z < grids[0] or z >= grids[-1]); NaN stays NaN."""
+    b = np.asarray(setup.bvf, dtype=np.float64)
+    g = setup.grids
+    z = np.asarray(z, dtype=np.float64)
+    slope = (b[1:] - b[:-1]) / (g[1:] - g[:-1])
+    j = np.clip(np.searchsorted(g, z, side="right") - 1, 0, len(g) - 2)
+    inside = (z >= g[0]) & (z < g[-1])
+    return np.where(np.isnan(z), np.nan, np.where(inside, slope[j], 0.0))
+
+
+# --------------------------------------------------------------------------
 # a-5  shear interpolation
 # --------------------------------------------------------------------------
 def shear_at_rays(setup, rr, uu, vv):
@@ -189,14 +224,15 @@ def wave_projection(dens, rr_low, rr_up, kk, ll, mm_low, mm_up, phi,
 def saturation(setup, dt, dens, rr_center, rr_center_st, drr, drr_st, kk, ll,
                mm_center, mm_center_st, direct=False):
     """lib/libprop.py:561-615"""
-    phi0, NN, kappa = setup.phi0, setup.bvf, setup.kappa
+    phi0, kappa = setup.phi0, setup.kappa
     ff = 2 * ROT_EARTH * np.sin(phi0)
     rr_final = rr_center + rr_center_st * dt
     drr_final = drr + drr_st * dt
     mm_final = mm_center + mm_center_st * dt
     dmm_final = setup.rr_mm_area / drr_final
     rhobar_final = np.interp(rr_final, setup.grids, setup.rhobar)
-    omh = omega(kk, ll, mm_center, phi0, NN)
+    NN = bvf_at(setup, rr_final)                         # scalar bvf: the reference's NN (:583)
+    omh = omega(kk, ll, mm_center, phi0, bvf_at(setup, rr_center))
     phase_volume = setup.dkk * setup.dll * dmm_final
     with np.errstate(divide='ignore', invalid='ignore'):
         max_dens_final = (kappa ** 2 * .5 * rhobar_final * omh * NN ** 2
@@ -224,12 +260,18 @@ def rhs(setup, dt, state, loop=False, fixed_background=False, return_flux=False,
     (2, ngrid-2) projection, e.g. a gloo all-reduce over ray shards.
     """
     dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = state
-    bvf = setup.bvf
-    cgr_up = cg_rr(kk, ll, mm, phi, bvf)                 # :635 (rr unused)
-    cgr_down = cg_rr(kk, ll, mm, phi, bvf)               # :636
+    ncol = np.ndim(setup.bvf) != 0                       # EXTENSION: N as a column on grids (see bvf_at)
+    if ncol and setup.hprop:
+        raise NotImplementedError("the N(z) column extension is defined for HPROP_GLOBAL = False only")
+    bvf = bvf_at(setup, rr)                              # scalar bvf: the scalar itself
+    cgr_up = cg_rr(kk, ll, mm, phi, bvf_at(setup, rr + .5 * drr))     # :635 (rr unused there: scalar bvf)
+    cgr_down = cg_rr(kk, ll, mm, phi, bvf_at(setup, rr - .5 * drr))   # :636
     zeros = np.zeros(np.shape(kk))
     du_dz_ray, dv_dz_ray = shear_at_rays(setup, rr, uu, vv)
     gradient = (kk * du_dz_ray + ll * dv_dz_ray)         # :517
+    if ncol:                                             # refraction by dN/dz (extension, see above)
+        gradient = gradient + (bvf * (kk ** 2 + ll ** 2) / omega(kk, ll, mm, phi, bvf)
+                               / (kk ** 2 + ll ** 2 + mm ** 2) * bvf_gradient_at(setup, rr))
     if setup.hprop:
         # HPROP_GLOBAL = True (lib/libprop.py:5, SURVEY 8f rank 3): horizontal propagation on the sphere
         om = omega(kk, ll, mm, phi, bvf)

@@ -5,6 +5,7 @@
 #include "column_kernels.h"
 #include "hprop_kernels.h"
 #include "misc_kernels.h"
+#include "nz_kernels.h"
 
 namespace msgw {
 
@@ -41,6 +42,17 @@ const void *hprop_kernel(int stage, bool sat)
     }
     return nullptr;
 }
+const void *nz_kernel(int stage, bool sat)
+{
+    switch (stage) {
+    case 0: return sat ? KPTR(k_ray_stage_nz<0, true>) : KPTR(k_ray_stage_nz<0, false>);
+    case 1: return sat ? KPTR(k_ray_stage_nz<1, true>) : KPTR(k_ray_stage_nz<1, false>);
+    case 2: return sat ? KPTR(k_ray_stage_nz<2, true>) : KPTR(k_ray_stage_nz<2, false>);
+    case 3: return sat ? KPTR(k_ray_stage_nz<3, true>) : KPTR(k_ray_stage_nz<3, false>);
+    }
+    return nullptr;
+}
+const void *nz_prepare_kernel() { return KPTR(k_nz_prepare); }
 const void *project_arrays_kernel(int np)
 {
     return np == 2 ? KPTR(k_project<double, 2, true, true>) : KPTR(k_project<double, 1, true, true>);

@@ -75,6 +75,16 @@ __global__ void k_rho_slopes(int nc, const double *grids, const double *rhobar, 
 }
 
 
+// dkk*dll (:137, :599) and rr_mm_area (:594) per ray, once per upload
+__global__ void k_nz_prepare(long long n, const double *dkk, const double *dll, const double *area, double *dkdl, double *area_out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dkdl[i] = dkk[i] * dll[i];
+    area_out[i] = area[i];
+}
+
+
 // Self-test of the node-level exchange, run once by every rank when the communicator is set up:
 // `rounds` node-level sums of known rows through the very code path of the persistent kernel.  A rank
 // that cannot see the others' rows (or sees them out of order) reports 0 and the host side falls

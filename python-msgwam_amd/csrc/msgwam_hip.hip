@@ -27,6 +27,7 @@
 #include "kernel_table.h"
 #include "column_kernels.h"
 #include "hprop_kernels.h"
+#include "nz_kernels.h"
 #include "persist_kernel.h"
 #include "ray_kernels.h"
 
@@ -134,6 +135,10 @@ struct msgw_ctx {
     double *lam = nullptr, *phi = nullptr, *q_lam = nullptr, *q_phi = nullptr, *q_kk = nullptr, *q_ll = nullptr;
     bool fvec = false;
     double f_uni = 0;
+    // EXTENSION: N as a column on grids (msgw_set_bvf_column): drr, dmm evolve too; a per-stage kernel of its own
+    int nz = 0;
+    bool have_nz = false;            // dkdl / area of the resident rays are in place
+    double *bvfcol = nullptr, *nz_q_drr = nullptr, *nz_q_dmm = nullptr, *nz_dkdl = nullptr, *nz_area = nullptr;
 
     // column
     double *colbuf = nullptr;
@@ -870,6 +875,8 @@ int ready(msgw_ctx *c)
     if (!c->have_column) return fail(c, MSGW_ERR_ARG, "msgw_set_column has not been called");
     if (!c->have_rays) return fail(c, MSGW_ERR_ARG, "msgw_upload_rays has not been called");
     if (c->hprop && !c->have_hprop) return fail(c, MSGW_ERR_ARG, "HPROP is on: msgw_upload_hprop (lam, phi) has not been called");
+    if (c->nz && !c->have_nz) return fail(c, MSGW_ERR_ARG, "an N(z) column is set: call msgw_upload_rays after msgw_set_bvf_column");
+    if (c->nz && c->hprop) return fail(c, MSGW_ERR_UNSUP, "the N(z) column extension is defined for HPROP_GLOBAL = False only");
     return MSGW_OK;
 }
 
@@ -903,6 +910,33 @@ int enqueue_steps_hprop(msgw_ctx *c, double dt, unsigned flags, int count)
     for (int step = 0; step < count; ++step)
         for (int s = 0; s < 3; ++s) {
             if (int rc = launch_hprop_stage(c, s, h)) return rc;
+            if (int rc = column_stage(c, s, ca)) return rc;
+        }
+    return MSGW_OK;
+}
+
+// ---- N(z) column extension: its own per-stage kernel + the standalone column kernel (float64 only)
+NzArgs make_nz_args(msgw_ctx *c, double dt, unsigned flags)
+{
+    NzArgs h{};
+    h.s = make_stage_args<double>(c, dt, flags);
+    h.drr = static_cast<double *>(c->drr); h.dmm = static_cast<double *>(c->dmm);
+    h.q_drr = c->nz_q_drr; h.q_dmm = c->nz_q_dmm; h.dkdl = c->nz_dkdl; h.area = c->nz_area; h.bvf = c->bvfcol;
+    return h;
+}
+
+int launch_nz_stage(msgw_ctx *c, int stage, const NzArgs &h)
+{
+    return launch_struct(c, nz_kernel(stage, c->sat_online != 0), c->blocks, BLOCK, hprop_lds_bytes(c), h);
+}
+
+int enqueue_steps_nz(msgw_ctx *c, double dt, unsigned flags, int count)
+{
+    const NzArgs h = make_nz_args(c, dt, flags);
+    const ColArgs ca = make_col_args(c, dt, flags);
+    for (int step = 0; step < count; ++step)
+        for (int s = 0; s < 3; ++s) {
+            if (int rc = launch_nz_stage(c, s, h)) return rc;
             if (int rc = column_stage(c, s, ca)) return rc;
         }
     return MSGW_OK;
@@ -1282,6 +1316,13 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
         rc = launch_list(c, prepare_kernel<double>(), pg, 256, (long long)n, (const double *)s_dkk, (const double *)s_dll,
                          (const double *)s_area, d_drr, d_dmm, static_cast<double *>(c->vol), static_cast<double *>(c->pvf));
     if (rc) return rc;
+    c->have_nz = false;
+    if (c->nz) {                                               // N(z) column: dkk*dll and rr_mm_area stay on the device
+        if (int rc4 = launch_list(c, nz_prepare_kernel(), pg, 256, (long long)n, (const double *)s_dkk, (const double *)s_dll,
+                                  (const double *)s_area, c->nz_dkdl, c->nz_area))
+            return rc4;
+        c->have_nz = true;
+    }
     // inert padding up to a whole tile (finite, never deposited: validity is index < n)
     const long long n_pad = ((n + c->tile - 1) / c->tile + 1) * c->tile;   // a workgroup's last tile may overhang by < TILE
     if (n_pad > n)
@@ -1331,6 +1372,51 @@ int msgw_download_hprop(msgw_ctx *c, int64_t n, int tendencies, double *lam, dou
     double *dst[4] = {lam, phi, kk, ll};
     for (int i = 0; i < 4; ++i)
         if (dst[i]) HIPCHK(c, hipMemcpyAsync(dst[i], src[i], B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSGW_OK;
+}
+
+int msgw_set_bvf_column(msgw_ctx *c, const double *bvf)
+{
+    if (!c) return MSGW_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!bvf) {                                                // back to the scalar of msgw_set_config
+        c->nz = 0;
+        return MSGW_OK;
+    }
+    if (c->f32) return fail(c, MSGW_ERR_UNSUP, "the N(z) column extension is float64 only");
+    const size_t nc = (size_t)c->ng - 1;
+    if (!c->bvfcol) {
+        const size_t padded = (((size_t)c->cap + c->tile - 1) / c->tile + 1) * c->tile;
+        HIPCHK(c, hipMalloc(&c->bvfcol, nc * sizeof(double)));
+        double **np_[] = {&c->nz_q_drr, &c->nz_q_dmm, &c->nz_dkdl, &c->nz_area};
+        for (double **p : np_) {
+            HIPCHK(c, hipMalloc(p, padded * sizeof(double)));
+            c->ray_bufs.push_back(*p);
+            HIPCHK(c, hipMemsetAsync(*p, 0, padded * sizeof(double), c->stream));
+        }
+        c->ray_bufs.push_back(c->bvfcol);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->bvfcol, bvf, nc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->nz) c->have_nz = false;                            // dkk*dll / rr_mm_area come with the next msgw_upload_rays
+    c->nz = 1;
+    drop_graph(c);
+    return MSGW_OK;
+}
+
+int msgw_download_extents(msgw_ctx *c, int64_t n, int tendencies, double *drr, double *dmm)
+{
+    if (!c || !c->have_rays) return fail(c, MSGW_ERR_ARG, "no rays resident");
+    if (n != c->n) return fail(c, MSGW_ERR_ARG, "n=%lld but %lld rays are resident", (long long)n, (long long)c->n);
+    if (tendencies && !c->nz) return fail(c, MSGW_ERR_ARG, "drr, dmm have tendencies only with an N(z) column");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = check_status(c)) return rc;
+    Staging st;
+    if (c->f32) HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)n * 2));
+    const void *s0 = tendencies ? (const void *)c->nz_q_drr : c->drr, *s1 = tendencies ? (const void *)c->nz_q_dmm : c->dmm;
+    if (drr) if (int rc = download_array(c, drr, s0, n, st.p)) return rc;
+    if (dmm) if (int rc = download_array(c, dmm, s1, n, st.p ? st.p + n : nullptr)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSGW_OK;
 }
@@ -1386,6 +1472,16 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
         c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
         return MSGW_OK;
     }
+    if (c->nz) {                                               // N(z) column extension: its own per-stage chain
+        if (flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK | MSGW_RELAUNCH))
+            return fail(c, MSGW_ERR_UNSUP, "the fused direct saturation and the relaunch extension are not "
+                        "available with an N(z) column");
+        c->cnt.persist_steps = 0;
+        if (int rc = enqueue_steps_nz(c, dt, gflags, nsteps)) return rc;
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
+        return MSGW_OK;
+    }
     if (int rc = c->f32 ? step_impl<float>(c, dt, nsteps, gflags, eager, time_kernels)
                         : step_impl<double>(c, dt, nsteps, gflags, eager, time_kernels))
         return rc;
@@ -1414,6 +1510,8 @@ int msgw_rhs(msgw_ctx *c, double dt, unsigned flags, double *st_dens, double *st
     if (c->hprop) {
         const HpropArgs h = make_hprop_args(c, dt, flags);
         if (int rc = launch_hprop_stage(c, 3, h)) return rc;
+    } else if (c->nz) {
+        if (int rc = launch_nz_stage(c, 3, make_nz_args(c, dt, flags))) return rc;
     } else if (c->f32) {
         if (int rc = launch_probe<float>(c, make_stage_args<float>(c, dt, flags), c->sat_online != 0, true)) return rc;
     } else {
@@ -1554,7 +1652,9 @@ struct msgw_snapshot {
     void *buf = nullptr;
     size_t bytes = 0;
     int64_t n = 0;
-    int hprop = 0;
+    size_t off[MSGW_SLOT_COUNT] = {0};     // byte offset of each slot in buf
+    size_t len[MSGW_SLOT_COUNT] = {0};     // bytes (0: not part of this snapshot)
+    int ray_typed[MSGW_SLOT_COUNT] = {0};  // stored in the ray type (float32 contexts: converted on download)
 };
 
 int msgw_snapshot_create(msgw_ctx *c, msgw_snapshot **out)
@@ -1563,10 +1663,16 @@ int msgw_snapshot_create(msgw_ctx *c, msgw_snapshot **out)
     *out = nullptr;
     if (!c->have_rays || !c->have_column) return fail(c, MSGW_ERR_ARG, "nothing resident to snapshot");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t ray = (size_t)c->n * c->esz, hp = (c->hprop && c->have_hprop) ? (size_t)c->n * sizeof(double) : 0;
+    const size_t ray = (size_t)c->n * c->esz, dbl = (size_t)c->n * sizeof(double);
     const size_t col = (size_t)(c->ng - 1) * sizeof(double);
-    const size_t bytes = 3 * ray + 4 * hp + 2 * col;
+    const bool hp = c->hprop && c->have_hprop, nz = c->nz && c->have_nz;
     msgw_snapshot *s = new msgw_snapshot();
+    const void *src[MSGW_SLOT_COUNT] = {c->dens, c->rr, c->mm, c->uu, c->vv, hp ? c->lam : nullptr, hp ? c->phi : nullptr,
+                                        hp ? c->kk : nullptr, hp ? c->ll : nullptr, nz ? c->drr : nullptr, nz ? c->dmm : nullptr};
+    const size_t len[MSGW_SLOT_COUNT] = {ray, ray, ray, col, col, dbl, dbl, ray, ray, ray, ray};
+    size_t bytes = 0;
+    for (int k = 0; k < MSGW_SLOT_COUNT; ++k)
+        if (src[k]) { s->off[k] = bytes; s->len[k] = len[k]; s->ray_typed[k] = len[k] == ray && k != MSGW_SLOT_UU && k != MSGW_SLOT_VV; bytes += (len[k] + 255) / 256 * 256; }
     for (size_t i = 0; i < c->snap_pool.size(); ++i)
         if (c->snap_pool[i].first >= bytes) {
             s->buf = c->snap_pool[i].second; s->bytes = c->snap_pool[i].first;
@@ -1577,44 +1683,29 @@ int msgw_snapshot_create(msgw_ctx *c, msgw_snapshot **out)
         if (hipMalloc(&s->buf, bytes) != hipSuccess) { delete s; return fail(c, MSGW_ERR_HIP, "hipMalloc of a snapshot failed"); }
         s->bytes = bytes;
     }
-    s->n = c->n; s->hprop = hp ? 1 : 0;
-    char *b = static_cast<char *>(s->buf);
-    const void *src[3] = {c->dens, c->rr, c->mm};
-    for (int i = 0; i < 3; ++i) HIPCHK(c, hipMemcpyAsync(b + i * ray, src[i], ray, hipMemcpyDeviceToDevice, c->stream));
-    b += 3 * ray;
-    if (hp) {
-        const void *hs[4] = {c->lam, c->phi, c->kk, c->ll};
-        for (int i = 0; i < 4; ++i) HIPCHK(c, hipMemcpyAsync(b + i * hp, hs[i], hp, hipMemcpyDeviceToDevice, c->stream));
-        b += 4 * hp;
-    }
-    HIPCHK(c, hipMemcpyAsync(b, c->uu, col, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(b + col, c->vv, col, hipMemcpyDeviceToDevice, c->stream));
+    s->n = c->n;
+    for (int k = 0; k < MSGW_SLOT_COUNT; ++k)
+        if (s->len[k])
+            HIPCHK(c, hipMemcpyAsync(static_cast<char *>(s->buf) + s->off[k], src[k], s->len[k], hipMemcpyDeviceToDevice, c->stream));
     *out = s;
     return MSGW_OK;
 }
 
-int msgw_snapshot_download(msgw_ctx *c, msgw_snapshot *s, double *dens, double *rr, double *mm, double *uu, double *vv,
-                           double *lam, double *phi, double *kk, double *ll)
+int msgw_snapshot_download(msgw_ctx *c, msgw_snapshot *s, int slot, double *out)
 {
-    if (!c || !s || !s->buf) return MSGW_ERR_ARG;
+    if (!c || !s || !s->buf || !out) return MSGW_ERR_ARG;
+    if (slot < 0 || slot >= MSGW_SLOT_COUNT || !s->len[slot]) return fail(c, MSGW_ERR_ARG, "slot %d is not part of this snapshot", slot);
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = check_status(c)) return rc;
-    const size_t ray = (size_t)s->n * c->esz, hp = s->hprop ? (size_t)s->n * sizeof(double) : 0;
-    const size_t col = (size_t)(c->ng - 1) * sizeof(double);
-    char *b = static_cast<char *>(s->buf);
-    Staging st;
-    if (c->f32 && (dens || rr || mm)) HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)s->n * 3));
-    double *dst[3] = {dens, rr, mm};
-    for (int i = 0; i < 3; ++i)
-        if (dst[i]) if (int rc = download_array(c, dst[i], b + i * ray, s->n, st.p ? st.p + (size_t)i * s->n : nullptr)) return rc;
-    b += 3 * ray;
-    if ((lam || phi || kk || ll) && !hp) return fail(c, MSGW_ERR_ARG, "this snapshot holds no HPROP slots");
-    double *hd[4] = {lam, phi, kk, ll};
-    for (int i = 0; i < 4; ++i)
-        if (hd[i]) HIPCHK(c, hipMemcpyAsync(hd[i], b + i * hp, hp, hipMemcpyDeviceToHost, c->stream));
-    b += 4 * hp;
-    if (uu) HIPCHK(c, hipMemcpyAsync(uu, b, col, hipMemcpyDeviceToHost, c->stream));
-    if (vv) HIPCHK(c, hipMemcpyAsync(vv, b + col, col, hipMemcpyDeviceToHost, c->stream));
+    const char *src = static_cast<const char *>(s->buf) + s->off[slot];
+    if (s->ray_typed[slot] && c->f32) {
+        Staging st;
+        HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)s->n));
+        if (int rc = download_array(c, out, src, s->n, st.p)) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MSGW_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(out, src, s->len[slot], hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSGW_OK;
 }

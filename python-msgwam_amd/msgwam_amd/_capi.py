@@ -29,7 +29,7 @@ EXPORTS = [
     "msgw_set_column", "msgw_upload_rays", "msgw_step", "msgw_rhs", "msgw_project",
     "msgw_project_arrays", "msgw_saturation", "msgw_download_rays", "msgw_download_column",
     "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters", "msgw_set_relaunch", "msgw_upload_hprop", "msgw_download_hprop",
-    "msgw_snapshot_create", "msgw_snapshot_download", "msgw_snapshot_destroy",
+    "msgw_snapshot_create", "msgw_snapshot_download", "msgw_snapshot_destroy", "msgw_set_bvf_column", "msgw_download_extents",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -85,7 +85,9 @@ def load_library():
     lib.msgw_upload_hprop.argtypes = [C.c_void_p, C.c_int64, _dp, _dp]
     lib.msgw_download_hprop.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp, _dp, _dp, _dp]
     lib.msgw_snapshot_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-    lib.msgw_snapshot_download.argtypes = [C.c_void_p, C.c_void_p] + [_dp] * 9
+    lib.msgw_snapshot_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _dp]
+    lib.msgw_set_bvf_column.argtypes = [C.c_void_p, _dp]
+    lib.msgw_download_extents.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp, _dp]
     lib.msgw_snapshot_destroy.argtypes = [C.c_void_p, C.c_void_p]
     if lib.msgw_abi_version() != 2:
         raise MsgwError("libmsgwam_hip.so has an unexpected ABI version")
@@ -168,6 +170,23 @@ class Propagator:
     def set_tuning(self, blocks_per_cu=4, graph_steps=0):
         self._chk(self.lib.msgw_set_tuning(self.ctx, int(blocks_per_cu), int(graph_steps)), "msgw_set_tuning")
 
+    def set_bvf_column(self, bvf):
+        """EXTENSION: N as a column on grids (None: back to the scalar of set_config).  Before upload_rays."""
+        if bvf is None:
+            self._chk(self.lib.msgw_set_bvf_column(self.ctx, None), "msgw_set_bvf_column")
+            return
+        b = _c(bvf)
+        if b.shape != (self.ngrid - 1,):
+            raise ValueError("the bvf column must have ngrid-1 values (on grids)")
+        self._chk(self.lib.msgw_set_bvf_column(self.ctx, _p(b)), "msgw_set_bvf_column")
+
+    def download_extents(self, tendencies=False, which=("drr", "dmm")):
+        """Slots 4, 8 (drr, dmm; they evolve only with an N(z) column), or their tendencies after rhs()."""
+        out = {k: np.empty(self.n) for k in which}
+        self._chk(self.lib.msgw_download_extents(self.ctx, self.n, int(bool(tendencies)), _p(out.get("drr")),
+                                                 _p(out.get("dmm"))), "msgw_download_extents")
+        return tuple(out[k] for k in which)
+
     def upload_hprop(self, lam, phi):
         """HPROP on: slots 1, 2 of the rays of the last upload_rays."""
         a = [_c(np.broadcast_to(x, (self.n,))) for x in (lam, phi)]
@@ -241,7 +260,7 @@ class Propagator:
         return tuple(out[k] for k in which)
 
     # -- snapshots (lazy host copies) ------------------------------------------
-    _SNAP_SLOTS = ("dens", "rr", "mm", "uu", "vv", "lam", "phi", "kk", "ll")
+    _SNAP_SLOTS = ("dens", "rr", "mm", "uu", "vv", "lam", "phi", "kk", "ll", "drr", "dmm")   # MSGW_SLOT_*
 
     def snapshot(self):
         """Stream-ordered device copy of the evolving slots; returns an opaque handle (release with snapshot_free)."""
@@ -252,8 +271,8 @@ class Propagator:
     def snapshot_download(self, snap, name):
         h, n = snap
         out = np.empty(self.ngrid - 1 if name in ("uu", "vv") else n)
-        args = [_p(out) if k == name else None for k in self._SNAP_SLOTS]
-        self._chk(self.lib.msgw_snapshot_download(self.ctx, h, *args), "msgw_snapshot_download")
+        self._chk(self.lib.msgw_snapshot_download(self.ctx, h, self._SNAP_SLOTS.index(name), _p(out)),
+                  "msgw_snapshot_download")
         return out
 
     def snapshot_free(self, snap):

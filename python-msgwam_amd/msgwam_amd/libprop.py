@@ -343,6 +343,13 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
 
 _EVOLVING = {0: "dens", 3: "rr", 7: "mm", 9: "uu", 10: "vv"}
 _EVOLVING_HPROP = {1: "lam", 2: "phi", 5: "kk", 6: "ll"}
+_EVOLVING_NZ = {4: "drr", 8: "dmm"}                         # with a bvf column (extension)
+
+
+def _bvf_column():
+    """The bvf column when model_config['bvf'] is one (extension), else None."""
+    b = model_config['bvf']
+    return None if np.ndim(b) == 0 else np.ascontiguousarray(b, dtype=np.float64)
 
 
 class _Backend:
@@ -406,6 +413,8 @@ class _Backend:
             return p.download_rays((a._name,))[0]
         if a._name in ("uu", "vv"):
             return p.download_column((a._name,))[0]
+        if a._name in ("drr", "dmm"):
+            return p.download_extents(which=(a._name,))[0]
         return dict(zip(("lam", "phi", "kk", "ll"), p.download_hprop()))[a._name]
 
     def reset(self, keep_device=False):
@@ -465,8 +474,12 @@ def set_residency(mode="safe"):
 def _check_scope():
     if grid is None or grids is None:
         raise RuntimeError("lprop.grid / lprop.grids are not set (raytracer.py:76-77)")
-    if np.ndim(model_config['bvf']) != 0:
-        raise NotImplementedError("only a scalar bvf is supported (as in the reference)")
+    b = model_config['bvf']
+    if np.ndim(b) != 0:                                          # EXTENSION: N as a column on grids
+        if np.shape(b) != np.shape(grids):
+            raise ValueError("model_config['bvf'] must be a scalar (as in the reference) or an array on lprop.grids")
+        if HPROP_GLOBAL:
+            raise NotImplementedError("a bvf column is supported with HPROP_GLOBAL = False only")
 
 
 def _same(a, b):
@@ -495,11 +508,13 @@ def _slot_resident(x, key):
 
 
 def _sync_config_and_column(p, uu, vv, force_uv):
-    cfg = (float(model_config['bvf']), float(model_config['phi0']), float(model_config['kappa']),
-           bool(model_config['saturate_online']), bool(HPROP_GLOBAL))
+    col = _bvf_column()
+    cfg = (float(model_config['bvf']) if col is None else col.tobytes(), float(model_config['phi0']),
+           float(model_config['kappa']), bool(model_config['saturate_online']), bool(HPROP_GLOBAL))
     if _backend.cfg != cfg:
         _backend.materialize_live()
-        p.set_config(cfg[0], cfg[1], cfg[2], cfg[3], hprop=cfg[4])
+        p.set_config(float(np.mean(col)) if col is not None else cfg[0], cfg[1], cfg[2], cfg[3], hprop=cfg[4])
+        p.set_bvf_column(col)                                    # (None: the scalar of set_config)
         _backend.cfg = cfg
         _backend.rays = None                                     # lam, phi must be (re)uploaded with the rays
     col = _backend.col
@@ -549,11 +564,13 @@ def _sync_rays(p, var):
 
 
 def _sync_config_only(p):
-    cfg = (float(model_config['bvf']), float(model_config['phi0']), float(model_config['kappa']),
-           bool(model_config['saturate_online']), bool(HPROP_GLOBAL))
+    col = _bvf_column()
+    cfg = (float(model_config['bvf']) if col is None else col.tobytes(), float(model_config['phi0']),
+           float(model_config['kappa']), bool(model_config['saturate_online']), bool(HPROP_GLOBAL))
     if _backend.cfg != cfg:
         _backend.materialize_live()
-        p.set_config(cfg[0], cfg[1], cfg[2], cfg[3], hprop=cfg[4])
+        p.set_config(float(np.mean(col)) if col is not None else cfg[0], cfg[1], cfg[2], cfg[3], hprop=cfg[4])
+        p.set_bvf_column(col)                                    # (None: the scalar of set_config)
         _backend.cfg = cfg
         _backend.rays = None
 
@@ -612,6 +629,9 @@ def _rhs(dt, var_in, flags):
     p = _prepare(var_in)
     t = p.rhs(dt, flags)
     z = lambda: np.zeros(np.shape(var_in[5]))
+    if _bvf_column() is not None:                                # N(z) column: ddrr_st, ddmm_st != 0 (:641, :645)
+        ddrr, ddmm = p.download_extents(tendencies=True)
+        return _pack([t['dens'], z(), z(), t['rr'], ddrr, z(), z(), t['mm'], ddmm, t['uu'], t['vv']])
     if HPROP_GLOBAL:                                             # lam, phi, kk, ll have tendencies too (:638-643)
         lam, phi, kk, ll = p.download_hprop(tendencies=True)
         return _pack([t['dens'], lam, phi, t['rr'], z(), kk, ll, t['mm'], z(), t['uu'], t['vv']])
@@ -659,6 +679,8 @@ def _rk3_device(dt, var, flags):
     moved = dict(_EVOLVING)                                      # slots whose device values have just changed
     if HPROP_GLOBAL:
         moved.update(_EVOLVING_HPROP)
+    if _bvf_column() is not None:
+        moved.update(_EVOLVING_NZ)
     if flags & _capi.FIXED_BACKGROUND:                           # the hook zeroes the tendencies of slots 9, 10
         moved.pop(9), moved.pop(10)
     _backend.gen["rays"] += 1

@@ -1,0 +1,156 @@
+"""-m gpu: EXTENSION -- buoyancy frequency as a column N(z) on grids (msgw_set_bvf_column; SURVEY 8f rank 4, north_star
+"U(z)/N2(z) column").  The reference has a scalar bvf only, so the height-dependent case is PARITY UNPINNED: the
+numpy restatement's definition (bvf_at / bvf_gradient_at) is what the GPU is held to.  The new code path IS pinned to
+the reference where it can be: with a constant column every expression reduces to lib/libprop.py's, and the kernel
+must reproduce the reference's goldens."""
+import numpy as np
+import pytest
+
+from oracle import msgwam_oracle as orc
+from helpers import STATE_KEYS, load, setup_from, state_from, relerr
+from gpu_helpers import gpu_state
+from msgwam_amd import _capi
+from test_gpu_parity import _random_case, check_state, prof_err
+from test_oracle_golden import nz_kat_case
+
+pytestmark = pytest.mark.gpu
+
+
+def make_prop_nz(setup, state, bvf_column, dtype="f64"):
+    dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = state
+    p = _capi.Propagator(len(setup.grid), len(dens), dtype=dtype)
+    p.set_config(float(np.mean(bvf_column)), setup.phi0, setup.kappa, setup.saturate_online)
+    p.set_bvf_column(bvf_column)
+    p.set_column(setup.grid, setup.grids, setup.rhobar, setup.pressure_gradient, uu, vv)
+    p.upload_rays(dens, rr, drr, kk, ll, mm, dmm, phi, setup.dkk, setup.dll, setup.rr_mm_area)
+    return p
+
+
+def gpu_state_nz(p, st):
+    out = gpu_state(p, st)
+    out[4], out[8] = p.download_extents()
+    return out
+
+
+@pytest.mark.parametrize("name", ["g1_rhs_f0_sat0", "g1_rhs_f0_sat1", "g1_rhs_f45_sat0", "g1_rhs_f45_sat1"])
+def test_constant_column_single_rhs_vs_reference_golden(name):
+    d = load(name)
+    s = setup_from(d)
+    p = make_prop_nz(s, state_from(d, "in"), np.full(len(s.grids), float(d["bvf"])))
+    out = p.rhs(float(d["dt"]))
+    for k in ("dens", "rr", "mm"):
+        assert relerr(out[k], d[f"out_{k}"]) <= 1e-12, k
+    ddrr, ddmm = p.download_extents(tendencies=True)
+    assert not np.any(ddrr) and not np.any(ddmm)             # cgr_up == cgr_down when N is constant (:641, :645)
+    assert prof_err(out["pm_flux"][:, 1:-1], d["pm_flux_inner"]) <= 1e-12
+    for k in ("uu", "vv"):
+        assert prof_err(out[k], d[f"out_{k}"]) <= 1e-12, k
+    p.close()
+
+
+@pytest.mark.parametrize("name,marks,flags", [("g3_rk3_coupled_f45", (1, 10, 100), 0), ("g4_saturation_online", (1, 5), 0),
+                                              ("g3_rk3_fixedbg_config1", (1, 100), _capi.FIXED_BACKGROUND)])
+def test_constant_column_rk3_vs_reference_golden(name, marks, flags):
+    d = load(name)
+    s = setup_from(d)
+    st = state_from(d, "in")
+    p = make_prop_nz(s, st, np.full(len(s.grids), float(d["bvf"])))
+    done = 0
+    for n in marks:
+        p.step(float(d["dt"]), n - done, flags)
+        done = n
+        got = gpu_state_nz(p, st)
+        check_state(got, state_from(d, f"s{n}"), 1e-10, 1e-10, (name, n))
+        assert np.array_equal(got[4], st[4]) and np.array_equal(got[8], st[8])   # drr, dmm do not move
+    assert p.counters()["persist_steps"] == 0                # a per-stage kernel of its own
+    p.close()
+
+
+def _column(grids, seed):
+    rng = np.random.default_rng(seed)
+    return 0.01 * (1 + 0.3 * np.sin(grids / 17e3 + rng.uniform(0, 6)) + 0.1 * grids / grids[-1])
+
+
+@pytest.mark.parametrize("n,seed,sat,phi_mode,sorted_z", [(3, 1, False, "uniform", False), (4097, 2, True, "vector", True),
+                                                         (60_001, 3, True, "uniform", False)])
+def test_height_dependent_column_vs_the_definition(n, seed, sat, phi_mode, sorted_z):
+    """Random N(z), coupled, online saturation, rays incl. below-ground / above-top (np.interp clamps): one RHS
+    (all 11 tendencies, drr and dmm included) at rtol 1e-12 and three steps at rtol 1e-10 against the numpy
+    restatement that defines the extension."""
+    s, st = _random_case(n, 40 + seed, sat, phi_mode, sorted_z)
+    col = _column(s.grids, seed)
+    s.bvf = col
+    want_t = orc.rhs(s, 60.0, st)
+    p = make_prop_nz(s, st, col)
+    t = p.rhs(60.0)
+    ddrr, ddmm = p.download_extents(tendencies=True)
+    got_t = {0: t["dens"], 3: t["rr"], 4: ddrr, 7: t["mm"], 8: ddmm}
+    for i, g in got_t.items():
+        scale = np.max(np.abs(want_t[i])) or 1.0
+        assert np.max(np.abs(g - want_t[i])) <= 1e-12 * scale, STATE_KEYS[i]
+    assert np.any(ddrr != 0.0)
+    for k, i in (("uu", 9), ("vv", 10)):
+        assert prof_err(t[k], want_t[i]) <= 1e-12, k
+    want = st
+    for _ in range(3):
+        want = orc.rk3(s, 60.0, want)
+    p.step(60.0, 1)
+    p.step(60.0, 2)
+    got = gpu_state_nz(p, st)
+    check_state(got, want, 1e-10, 1e-11, ("N(z)", n))
+    for i in (4, 8):
+        assert relerr(got[i], want[i]) <= 1e-10, STATE_KEYS[i]
+    p.close()
+
+
+def test_kat_frequency_conservation_on_the_gpu():
+    """The known-answer test of the extension (tests/test_oracle_golden.py) on the GPU: omega is conserved along the
+    rays to the time-stepping error while m changes by several per cent."""
+    s, st = nz_kat_case(n=5000, seed=7)
+    om0 = orc.omega(st[5], st[6], st[7], st[2], orc.bvf_at(s, st[3]))
+    p = make_prop_nz(s, st, s.bvf)
+    p.step(60.0, 120, _capi.FIXED_BACKGROUND)
+    got = gpu_state_nz(p, st)
+    p.close()
+    om = orc.omega(got[5], got[6], got[7], got[2], orc.bvf_at(s, got[3]))
+    assert np.max(np.abs(om / om0 - 1)) <= 1e-5
+    assert np.max(np.abs(got[7] / st[7] - 1)) >= 0.03 and np.max(np.abs(got[4] / st[4] - 1)) >= 0.01
+    assert np.allclose(got[8] / got[4], st[8] / st[4], rtol=1e-12)
+
+
+def test_bvf_column_through_the_module_surface_and_scope():
+    """`model_config['bvf']` as an array on lprop.grids: RK3 and rhs_default return drr, dmm as evolving slots;
+    float32 contexts and the fused direct saturation say that they do not support the extension."""
+    import msgwam_amd.libprop as lprop
+    s, st = _random_case(2000, 55, True, "uniform", True)
+    col = _column(s.grids, 5)
+    s.bvf = col
+    lprop.HPROP_GLOBAL = False
+    lprop.set_model_setup(bvf=col, rhs=lprop.rhs_default, phi0=s.phi0, kappa=s.kappa, saturate_online=True)
+    lprop.grid, lprop.grids, lprop.rhobar, lprop.pressure_gradient = s.grid, s.grids, s.rhobar, s.pressure_gradient
+    lprop.set_statics(dkk=s.dkk, dll=s.dll, rr_mm_area=s.rr_mm_area)
+    try:
+        var = np.empty(11, dtype=object)
+        for i, a in enumerate(st):
+            var[i] = a
+        t = lprop.rhs_default(60.0, var)
+        want_t = orc.rhs(s, 60.0, st)
+        for i in (3, 4, 7, 8):
+            assert np.max(np.abs(np.asarray(t[i]) - want_t[i])) <= 1e-12 * (np.max(np.abs(want_t[i])) or 1.0), i
+        out = lprop.RK3(60.0, var)
+        out = lprop.RK3(60.0, out)
+        assert isinstance(out[4], lprop.DeviceArray) and isinstance(out[8], lprop.DeviceArray)
+        want = orc.rk3(s, 60.0, orc.rk3(s, 60.0, st))
+        for i in (0, 3, 4, 7, 8):
+            assert relerr(np.asarray(out[i]), want[i]) <= 1e-10, i
+    finally:
+        lprop.set_model_setup(bvf=0.01, saturate_online=True)
+        lprop.release_device()
+    p = make_prop_nz(s, st, col)
+    with pytest.raises(_capi.MsgwError, match="not available with an N"):
+        p.step(60.0, 1, _capi.RELAUNCH)
+    p.close()
+    p32 = _capi.Propagator(len(s.grid), 100, dtype="f32")
+    with pytest.raises(_capi.MsgwError, match="float64 only"):
+        p32.set_bvf_column(col)
+    p32.close()

@@ -7,6 +7,8 @@ Tolerances (fp64; north_star: per-ray state within rtol 1e-10):
   * flux profile / mean-flow tendencies: |err| <= 1e-12 * max|profile| (reduction order differs)
   * multi-step well-posed horizons: rtol 1e-10     (P2/P3)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -400,3 +402,36 @@ def test_persistent_kernel_equals_per_stage_kernels(monkeypatch):
     check_state(outs["1"], outs["0"], 1e-11, 1e-11, "persist-vs-per-stage")
     want = COracle(s).step(60.0, 43, st)
     check_state(outs["1"], want, 1e-9, 1e-9, "persist-vs-oracle")
+
+
+@pytest.mark.parametrize("ngrid", [5, 6, 9])
+def test_smallest_columns_vs_c_oracle(ngrid):
+    """ngrid = 5 is the smallest column the library accepts (the scratch of the fused mean-flow update, 6*ngrid - 6
+    doubles, aliases the 8*(ngrid - 2) doubles of the per-wave flux rows in LDS; msgw_create rejects ngrid < 5):
+    persistent kernel and launch chain against the C oracle."""
+    rng = np.random.default_rng(100 + ngrid)
+    n = 5_003
+    grid = np.linspace(0, 40e3, ngrid)
+    area = rng.uniform(1e-3, 1e-1, n)
+    s = orc.Setup(grid, phi0=0.3, kappa=0.9, dkk=np.full(n, 1e-4), dll=np.full(n, 1e-4), rr_mm_area=area)
+    uu = orc.velocities_sine_homogeneous(s.grids, 4.0, 20e3, 10e3)
+    vv = 0.2 * uu[::-1].copy()
+    s.set_pressure_gradient(uu, vv)
+    rr = np.sort(rng.uniform(-2e3, 42e3, n))
+    drr = rng.uniform(50, 3000, n)
+    st = [rng.uniform(0, 1e8, n), np.zeros(n), np.full(n, 0.3), rr, drr, rng.normal(0, 1e-4, n), rng.normal(0, 1e-4, n),
+          rng.normal(0, 2e-3, n), area / drr, uu, vv]
+    want = COracle(s).step(60.0, 3, st)
+    for env in ({}, {"MSGW_PERSIST": "0"}):
+        old = os.environ.get("MSGW_PERSIST")
+        os.environ.update(env)
+        try:
+            p = make_prop(s, st)
+            p.step(60.0, 3)
+            assert p.counters()["persist_steps"] == (0 if env else 3)
+            check_state(gpu_state(p, st), want, 1e-10, 1e-11, (ngrid, env))
+            p.close()
+        finally:
+            os.environ.pop("MSGW_PERSIST", None) if old is None else os.environ.__setitem__("MSGW_PERSIST", old)
+    with pytest.raises(_capi.MsgwError, match="ngrid >= 5"):
+        _capi.Propagator(4, 100)

@@ -215,3 +215,97 @@ def test_projection_interface_variants_bit_exact():
                                       r["mm"] - .5 * r["dmm"], r["mm"] + .5 * r["dmm"], r["phi"], r["dkk"], r["dll"],
                                       r["dmm"], G, float(d["bvf"]), var=var)
             assert np.array_equal(got, d[f"rand_{gname}_var{var}"]), (gname, var)
+
+
+def test_strong_amplitude_fixture_amplifies_summation_order_noise():
+    """Why GPU parity on g4_saturation_online is asserted at steps 1 and 5 only (tests/test_gpu_parity.py):
+    the strongly forced coupled system amplifies round-off.  Two runs of the SAME oracle on the SAME rays that differ
+    only in the order in which the rays are stored (hence in the order of the flux sums, ~1e-16 relative) drift apart
+    by about a decade per step until they saturate at O(1e-3) -- any implementation with its own summation order
+    (the GPU's tree, a different ray order, another BLAS) sees the same growth."""
+    d = load("g4_saturation_online")
+    s = setup_from(d)
+    st = state_from(d, "in")
+    n = len(st[0])
+    perm = np.random.default_rng(0).permutation(n)
+    s2 = orc.Setup(d["grid"], bvf=float(d["bvf"]), phi0=float(d["phi0"]), kappa=float(d["kappa"]),
+                   saturate_online=True, dkk=d["dkk"][perm], dll=d["dll"][perm], rr_mm_area=d["area"][perm])
+    s2.pressure_gradient = d["pg"].copy()
+    a = st
+    b = [x[perm] if x.shape == (n,) else x for x in st]
+    errs = []
+    for step in range(1, 13):
+        a = orc.rk3(s, float(d["dt"]), a)
+        b = orc.rk3(s2, float(d["dt"]), b)
+        errs.append(max(relerr(b[3], a[3][perm]), relerr(b[7], a[7][perm])))
+    errs = np.array(errs)
+    assert errs[0] <= 1e-13                                  # one step: round-off only
+    assert errs[4] <= 1e-10                                  # step 5: still inside the parity tolerance
+    assert errs[-1] >= 1e-9                                  # a few steps later it no longer is
+    growth = (errs[9] / max(errs[1], 1e-17)) ** (1 / 8)      # mean factor per step over steps 2..10
+    assert 2.0 <= growth <= 100.0, (growth, errs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# EXTENSION: N as a column on grids (oracle.bvf_at; the reference has a scalar only: parity unpinned except in the
+# constant-N limit, which these tests pin to the reference's goldens)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g1_rhs_f0_sat0", "g1_rhs_f0_sat1", "g1_rhs_f45_sat0", "g1_rhs_f45_sat1"])
+def test_bvf_column_constant_limit_single_rhs_is_the_reference(name):
+    d = load(name)
+    s = setup_from(d)
+    s.bvf = np.full(len(s.grids), float(d["bvf"]))
+    out, flux = orc.rhs(s, float(d["dt"]), state_from(d, "in"), return_flux=True)
+    for k, a in zip(STATE_KEYS, out):
+        assert np.array_equal(a, d[f"out_{k}"]), k
+    assert np.array_equal(flux[:, 1:-1], d["pm_flux_inner"])
+
+
+@pytest.mark.parametrize("name,marks", [("g3_rk3_coupled_f45", (1, 10)), ("g4_saturation_online", (1, 5)),
+                                        ("g3_rk3_fixedbg_config1", (1, 10, 100))])
+def test_bvf_column_constant_limit_rk3_is_the_reference(name, marks):
+    d = load(name)
+    s = setup_from(d)
+    s.bvf = np.full(len(s.grids), float(d["bvf"]))
+    cur, done = state_from(d, "in"), 0
+    for n in marks:
+        for _ in range(n - done):
+            cur = orc.rk3(s, float(d["dt"]), cur, fixed_background="fixedbg" in name)
+        done = n
+        for k, a in zip(STATE_KEYS, cur):
+            assert relerr(a, d[f"s{n}_{k}"]) <= 1e-12 or np.allclose(a, d[f"s{n}_{k}"], rtol=0, atol=1e-300), (n, k)
+
+
+def nz_kat_case(n=64, seed=1):
+    """Rays in a resting atmosphere with N**2 linear in height (N**2 = 1e-4 * (1 + z / 40 km)), frozen mean flow."""
+    grid = np.linspace(0, 60e3, 121)
+    s = orc.Setup(grid, bvf=0.01, phi0=0.3, dkk=np.full(n, 1e-4), dll=np.full(n, 1e-4), rr_mm_area=np.full(n, 1e-2))
+    s.bvf = np.sqrt(1e-4 * (1 + s.grids / 40e3))
+    zc = np.zeros(len(s.grids))
+    rng = np.random.default_rng(seed)
+    rr, drr = rng.uniform(5e3, 20e3, n), np.full(n, 200.0)
+    kk, ll = rng.normal(0, 1e-4, n), rng.normal(0, 1e-4, n)
+    mm = -np.abs(rng.normal(2e-3, 3e-4, n))
+    st = [np.full(n, 1.0), np.zeros(n), np.full(n, 0.3), rr, drr, kk, ll, mm, 1e-2 / drr, zc, zc.copy()]
+    return s, st
+
+
+def test_bvf_column_kat_frequency_is_conserved_in_a_steady_column():
+    """KAT of the extension: in a steady, resting background the intrinsic frequency omega(k, l, m, N(z)) is constant
+    along a ray, so m must follow the local dispersion relation as the ray climbs into larger N (the dN/dz term of
+    dm/dt); the ray volume stretches (ddrr_st = cgr_up - cgr_down) and lib/libprop.py:645 moves dmm with it."""
+    s, st = nz_kat_case()
+    om0 = orc.omega(st[5], st[6], st[7], st[2], orc.bvf_at(s, st[3]))
+    cur = st
+    for _ in range(120):
+        cur = orc.rk3(s, 60.0, cur, fixed_background=True)
+    om = orc.omega(cur[5], cur[6], cur[7], cur[2], orc.bvf_at(s, cur[3]))
+    assert np.max(np.abs(om / om0 - 1)) <= 1e-5              # 3e-6 at dt = 60 s (1e-6 at 30 s): time stepping only
+    assert np.max(np.abs(cur[7] / st[7] - 1)) >= 0.03        # while m itself changed by several per cent
+    assert np.min(cur[3] - st[3]) > 100.0                    # every ray moved up
+    assert np.max(np.abs(cur[4] / st[4] - 1)) >= 0.01        # drr evolved ...
+    assert np.allclose(cur[8] / cur[4], st[8] / st[4], rtol=1e-12)   # ... and dmm / drr stayed constant (:645 as written)
+    # without the column (scalar N) nothing of this happens: m, drr, dmm are constant in a resting atmosphere
+    s.bvf = 0.01
+    ref = orc.rk3(s, 60.0, st, fixed_background=True)
+    assert np.array_equal(ref[7], st[7]) and np.array_equal(ref[4], st[4]) and np.array_equal(ref[8], st[8])
