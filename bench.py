@@ -324,13 +324,13 @@ def main():
         if kern_ms:
             achieved = per_launch_bytes / (kern_ms * 1e-3) / 1e9
             # HBM bytes actually moved per launch: committed rocprofv3 PMC result (profiles/traffic.json, separate
-            # --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), keyed by workload:dtype:rays
+            # --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), keyed by workload:dtype:rays:resident tiles
             traffic, traffic_note = None, None
-            key = f"{wl}:{W['dtype']}:{n_local}"
+            key = f"{wl}:{W['dtype']}:{n_local}:res{c1.get('persist_resident_tiles', 0)}"
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             try:
                 t = json.load(open(tpath)).get(key)
-                if isinstance(t, dict) and persist_steps and t.get("resident_tiles") == c1.get("persist_resident_tiles", 0):
+                if isinstance(t, dict) and persist_steps:
                     traffic = t["bytes_per_ray_step"] * n_local * persist_steps
                     traffic_note = t.get("source")
                 else:

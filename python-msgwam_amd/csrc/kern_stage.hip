@@ -18,14 +18,14 @@ static const void *pick_form(int form)
 {
     constexpr bool GR = DEPOSIT && STAGE != 3;
     switch (form) {
-    case FORM_TALL: return KPTR(k_ray_stage<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, 0, false, false, RL>);
     case FORM_LAG:
-        if constexpr (GR) return KPTR(k_ray_stage<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, true, true, RL>);
+        if constexpr (GR) return KPTR(k_ray_stage<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, true, true, RL>);
         else return nullptr;
     case FORM_GROUP:
-        if constexpr (GR) return KPTR(k_ray_stage<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, true, false, RL>);
+        if constexpr (GR) return KPTR(k_ray_stage<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, true, false, RL>);
         else return nullptr;
-    case FORM_PLAIN: return KPTR(k_ray_stage<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, 2, false, false, RL>);
+    case FORM_TALL:              // tall columns take the same kernel (the level window is relative)
+    case FORM_PLAIN: return KPTR(k_ray_stage<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, false, false, RL>);
     }
     return nullptr;
 }

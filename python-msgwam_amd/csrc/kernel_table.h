@@ -8,7 +8,7 @@
 namespace msgw {
 
 // `form` of a ray-stage kernel
-constexpr int FORM_TALL = 0;     // NH = 0: level sums in LDS (columns with more than 128 levels), sparse rows
+constexpr int FORM_TALL = 0;     // columns with more than 128 levels: sparse rows (the same kernel as FORM_PLAIN)
 constexpr int FORM_LAG = 1;      // lagged launch chain: deposits the state it produces, in-kernel group reduction
 constexpr int FORM_GROUP = 2;    // fused chain: deposits its input state, in-kernel group reduction
 constexpr int FORM_PLAIN = 3;    // sparse per-workgroup rows (probe, tall-column chain)

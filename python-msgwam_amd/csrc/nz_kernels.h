@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_nz(const NzArgs h)
     const long long start = (long long)blockIdx.x * a.rays_per_block;
     const long long end = min(a.n, start + a.rays_per_block);
     int wmin = INT_MAX, wmax = INT_MIN;
-    double acc[2][1] = {{0.0}, {0.0}};
+    DepWindow acc;
+    acc.clear();
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = start + (long long)t * TILE;
         if (base >= end) break;
@@ -154,9 +155,10 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_nz(const NzArgs h)
                 }
             }
         }
-        deposit_tile<2, 0, double>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
+        deposit_tile<2, double>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
                                    ncp, lane, wmin, wmax, acc);
     }
+    flush_window(acc, s_rows + wave * 2 * ncp, ncp, lane);
     flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
 }
 

@@ -570,7 +570,7 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
     __syncthreads();
     int wmin = INT_MAX, wmax = INT_MIN;
     const StageLds<T> SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
-    process_tiles<T, STAGE, SAT, FVEC, true, DIRECT, 2, true, NRES, RL>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax, &res);
+    process_tiles<T, STAGE, SAT, FVEC, true, DIRECT, true, NRES, RL>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax, &res);
     PSTAMP(q, 2);
     persist_publish(p, L.rows, ncp, L.flag, tid, q + 1u);     // this pass produced state_{q+1}: publish F_{q+1}
     PSTAMP(q, 3);
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
         __syncthreads();
         const StageLds<T> SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
         // (with resident tiles: also leaves cg_rr of the initial state of the streamed tiles in memory)
-        deposit_pass<T, FVEC, 2, (NRES > 0 && !SAT && !DIRECT)>(a, SL, start, end, tid, wave, lane, start + (long long)NRES * TILE);
+        deposit_pass<T, FVEC, (NRES > 0 && !SAT && !DIRECT)>(a, SL, start, end, tid, wave, lane, start + (long long)NRES * TILE);
         persist_publish(p, L.rows, ncp, L.flag, tid, 0u);
     }
     // resident tiles: everything a stage may read (stage 2 of the DIRECT variant reads the most); lanes

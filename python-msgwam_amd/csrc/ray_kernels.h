@@ -125,7 +125,9 @@ typedef StageArgsT<double> StageArgs;
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v)
 {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+    // every lane of these patterns has a valid source, so the "old" value is never used: with bound_ctrl and an
+    // undefined old the compiler emits the bare v_mov_b32_dpp (no copy in front) and can fold it into a 32-bit VALU op
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
@@ -192,6 +194,31 @@ __device__ __forceinline__ void wave_sum2(double a, double b, double &ta, double
     v = __hiloint2double((int)rhi.x, (int)rlo.x) + __hiloint2double((int)rhi.y, (int)rlo.y);
     ta = readlane_f64(v, 0);
     tb = readlane_f64(v, 32);
+}
+// The same two sums, left IN the wave: every lane of 0-31 holds sum(a), every lane of 32-63 holds sum(b).
+__device__ __forceinline__ double wave_sum2_halves(double a, double b)
+{
+    const u32x2_t lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const u32x2_t hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    double v = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+    v = v + dpp_f64<0xB1>(v);
+    v = v + dpp_f64<0x4E>(v);
+    v = v + dpp_f64<0x141>(v);
+    v = v + dpp_f64<0x140>(v);
+    const u32x2_t rlo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const u32x2_t rhi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return __hiloint2double((int)rhi.x, (int)rlo.x) + __hiloint2double((int)rhi.y, (int)rlo.y);
+}
+__device__ __forceinline__ float wave_sum2_halves(float a, float b)
+{
+    const u32x2_t s = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    float v = __uint_as_float(s.x) + __uint_as_float(s.y);
+    v = v + dpp_f32<0xB1>(v);
+    v = v + dpp_f32<0x4E>(v);
+    v = v + dpp_f32<0x141>(v);
+    v = v + dpp_f32<0x140>(v);
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 // float32 form of the same butterfly: one dword per value, and the DPP steps fold into v_add_f32_dpp
 // (about 10 instructions for both sums).  Same fixed order.
@@ -303,22 +330,41 @@ __device__ __forceinline__ void deposit_indices(T lo, T up, bool valid, T dz, T 
     if (ood || !valid) { nlo = 0; nup = 0; }                 // :135, :153-154
 }
 
-// NH > 0: the wave keeps its level sums in NH lane-distributed float64 registers per payload (lane L of
-// register h owns level 64*h + L), so the per-level result of the DPP reduction is added with a
-// predicated VALU add instead of a lane-0 LDS read-modify-write; flush_acc() folds them into the
-// wave's LDS row once per workgroup.  NH == 0 (columns with more than 128 levels): LDS RMW.
-// T = float: weights, payloads and the 64-lane butterfly are float32; everything from the per-level
-// wave sum onwards (registers, LDS rows, workgroup rows) is float64.
+// Per-level sums of a wave.  NP = 2 (the pseudo-momentum fluxes of the RHS): the 64-lane butterfly leaves sum(a) in
+// every lane of 0-31 and sum(b) in every lane of 32-63 (wave_sum2_halves), and ONE float64 register per lane keeps the
+// wave's sums of a WINDOW of 32 levels: lane L owns level base + (L & 31) of payload L >> 5, so adding a level's sums
+// is a compare, a select and an add (round 1: lane-0 read-outs, a broadcast and a select chain over absolute-level
+// registers -- 28 instructions per level, as many as the butterfly).  The window is wave-uniform and moves with the
+// rays (flush_window folds it into the wave's private LDS row: 64 distinct addresses, no conflict); a pass of
+// neighbouring tiles practically never leaves it, and columns of any height take the same path.
+// NP = 1 (diagnostic projections): plain butterfly, lane 0 adds to the LDS row.
+// T = float: weights, payloads and the butterfly are float32; the window register and the rows are float64.
+struct DepWindow {
+    int base;                     // wave-uniform first level of the window; -1: empty
+    double v;                     // lane L: sum of level base + (L & 31), payload L >> 5
+    __device__ __forceinline__ void clear() { base = -1; v = 0.0; }
+};
+constexpr int DEP_WIN = 32;
 #ifdef MSGW_DBG_LEVELS
 __device__ unsigned long long g_dbg_levels, g_dbg_tiles, g_dbg_wide;
 #endif
-template <int NP, int NH, typename T>
+
+__device__ __forceinline__ void flush_window(DepWindow &W, double *row, int ncp, int lane)
+{
+    if (W.base >= 0) {                                       // wave-uniform
+        const int c = W.base + (lane & 31);
+        if (c < ncp) row[(lane >> 5) * ncp + c] += W.v;
+    }
+    W.clear();
+}
+
+template <int NP, typename T>
 __device__ __forceinline__ void deposit_tile(const T (&lo)[Real<T>::RPT], const T (&up)[Real<T>::RPT],
                                              const int (&nlo)[Real<T>::RPT], const int (&nup)[Real<T>::RPT],
                                              const T (&vol)[Real<T>::RPT], const T (&pay)[NP][Real<T>::RPT],
                                              const T *sG, T dz, T cdz, int ok,
                                              double *row, int ncp, int lane, int &wmin, int &wmax,
-                                             double (&acc)[NP][NH > 0 ? NH : 1])
+                                             DepWindow &W)
 {
     constexpr int RPT = Real<T>::RPT;
     int mylo = INT_MAX, myhi = INT_MIN;
@@ -342,6 +388,11 @@ __device__ __forceinline__ void deposit_tile(const T (&lo)[Real<T>::RPT], const 
     return;
 #endif
     if (whi - wlo <= SPAN_MAX) {
+        if (NP == 2) {
+            if (W.base >= 0 && (wlo < W.base || whi > W.base + DEP_WIN)) flush_window(W, row, ncp, lane);
+            if (W.base < 0) W.base = max(wlo - (DEP_WIN - SPAN_MAX) / 2, 0);    // room to drift both ways
+        }
+        const int mylevel = lane & 31;
         for (int c = wlo; c < whi; ++c) {                    // uniform trip count: all lanes stay
             const T g0 = sG[c], g1 = sG[c + 1];              // LDS broadcast reads
             T s[NP];
@@ -356,20 +407,12 @@ __device__ __forceinline__ void deposit_tile(const T (&lo)[Real<T>::RPT], const 
 #pragma unroll
                 for (int p = 0; p < NP; ++p) s[p] = s[p] + (in ? wv * pay[p][r] : T(0));
             }
-            T tsum[NP];
-            if (NP == 2) wave_sum2(s[0], s[NP - 1], tsum[0], tsum[NP - 1]);
-            else tsum[0] = wave_sum(s[0]);
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const double t = (double)tsum[p];
-                if (NH > 0) {
-                    const double mine = (lane == (c & 63)) ? t : 0.0;
-#pragma unroll
-                    for (int h = 0; h < NH; ++h)
-                        if ((c >> 6) == h) acc[p][h] = acc[p][h] + mine;     // uniform branch
-                } else if (lane == 0) {
-                    row[p * ncp + c] += t;
-                }
+            if (NP == 2) {
+                const double t = (double)wave_sum2_halves(s[0], s[NP - 1]);
+                W.v = W.v + ((mylevel == c - W.base) ? t : 0.0);
+            } else {
+                const double t = (double)wave_sum(s[0]);
+                if (lane == 0) row[c] += t;
             }
         }
     } else {
@@ -387,21 +430,6 @@ __device__ __forceinline__ void deposit_tile(const T (&lo)[Real<T>::RPT], const 
             }
         }
     }
-}
-
-// fold a wave's register accumulators into its LDS row (after its own LDS atomics, in order)
-template <int NP, int NH>
-__device__ __forceinline__ void flush_acc(double *row, int ncp, int lane,
-                                          const double (&acc)[NP][NH > 0 ? NH : 1])
-{
-    if (NH == 0) return;
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const int c = 64 * h + lane;
-            if (c < ncp) row[p * ncp + c] += acc[p][h];
-        }
 }
 
 // Sum the WAVES private rows in wave order and write this workgroup's row
@@ -656,7 +684,7 @@ struct StageCarve {
 // deposit the state this stage has just PRODUCED, i.e. the next stage's wave_projection input.
 // Same values (cg_rr is re-evaluated from the same kk, ll, new mm the next stage will load), but the
 // flux of stage q+1 is then published one whole pass before it is needed.
-template <typename T, int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH, bool LAG = false, int NRES = 0,
+template <typename T, int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool LAG = false, int NRES = 0,
           bool RELAUNCH = false>
 __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const StageLds<T> L, TileRegs<T> &cur,
                                               long long start, long long end, int tid, int wave,
@@ -676,11 +704,8 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
     // with resident tiles the kernel is FP64-VALU bound, not HBM bound: streamed tiles then carry cg_rr of
     // their state through memory (8 B store + 8 B load per ray-stage) instead of re-evaluating it
     constexpr bool CGMEM = NRES > 0 && LAG && DEPOSIT && !SAT && !DIRECT;
-    double acc[2][NH > 0 ? NH : 1];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int h = 0; h < (NH > 0 ? NH : 1); ++h) acc[p][h] = 0.0;
+    DepWindow acc;                                           // the wave's level sums of this pass
+    acc.clear();
     // resident tiles first: they are the workgroup's first NRES tiles, so the deposit order is ray order
     if constexpr (NRES > 0) {
         static_assert(NRES == 0 || STAGE != 3, "the single-RHS probe has no resident tiles");
@@ -710,12 +735,12 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
         MSGW_STAMP_AT(3 + 2 * (t & 1));
         if (more) load_tile<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, CGMEM>(cur, a, base + TILE, tid, end);
     }
-    if (DEPOSIT) flush_acc<2, NH>(s_rows + wave * 2 * ncp, ncp, lane, acc);
+    if (DEPOSIT) flush_window(acc, s_rows + wave * 2 * ncp, ncp, lane);
 }
 
 // Deposit-only pass over this workgroup's rays (no stores): wave_projection(var=0) of the CURRENT
 // state into the per-wave LDS rows.  Seeds the lagged-deposit pipeline of the persistent kernel.
-template <typename T, bool FVEC, int NH, bool CGSTORE = false>
+template <typename T, bool FVEC, bool CGSTORE = false>
 __device__ __forceinline__ void deposit_pass(const StageArgsT<T> a, const StageLds<T> L, long long start, long long end,
                                              int tid, int wave, int lane, long long cg_from = 0)
 {
@@ -723,11 +748,8 @@ __device__ __forceinline__ void deposit_pass(const StageArgsT<T> a, const StageL
     constexpr int TILE = Real<T>::TILE;
     const int nc = a.ng - 1, ncp = a.ng - 2;
     int wmin = INT_MAX, wmax = INT_MIN;
-    double acc[2][NH > 0 ? NH : 1];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int h = 0; h < (NH > 0 ? NH : 1); ++h) acc[p][h] = 0.0;
+    DepWindow acc;
+    acc.clear();
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = start + (long long)t * TILE;
         if (base >= end) break;
@@ -755,10 +777,10 @@ __device__ __forceinline__ void deposit_pass(const StageArgsT<T> a, const StageL
             pay[1][r] = cgr * ll[r] * dens[r];
         }
         if (CGSTORE && valid[0] && base >= cg_from) storev(a.r.cg(), off, cg2);   // streamed tiles of the persistent kernel
-        deposit_tile<2, NH, T>(lo, up, nlo, nup, vol, pay, L.gs, a.dzs, a.inv_dzs, a.mk_ok,
-                               L.rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
+        deposit_tile<2, T>(lo, up, nlo, nup, vol, pay, L.gs, a.dzs, a.inv_dzs, a.mk_ok,
+                           L.rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
     }
-    flush_acc<2, NH>(L.rows + wave * 2 * ncp, ncp, lane, acc);
+    flush_window(acc, L.rows + wave * 2 * ncp, ncp, lane);
 }
 
 // stage the static tables of the column (float64 in global memory) into the LDS views
@@ -803,7 +825,7 @@ __device__ __forceinline__ void pack_shear_table(typename Real<T>::quad_t *sh, c
 // extra VGPRs cost a wave of occupancy, capping it at 128 VGPRs spilled, and every spill reload
 // carries s_waitcnt vmcnt(0), which drains the prefetch.  The other resident workgroups cover
 // a workgroup's load latency instead.)
-template <typename T, int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, int NH = 2, bool GROUPRED = false,
+template <typename T, int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT, bool GROUPRED = false,
           bool LAG = false, bool RELAUNCH = false>
 __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgsT<T> a)
 {
@@ -870,7 +892,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage(const StageArgsT<T> a)
 
     int wmin = INT_MAX, wmax = INT_MIN;
     const StageLds<T> L{C.sh, C.rho2, C.xg, C.gs, s_rows};
-    process_tiles<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, NH, LAG, 0, RELAUNCH>(a, L, cur, start, end, tid, wave, lane, wmin, wmax);
+    process_tiles<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, LAG, 0, RELAUNCH>(a, L, cur, start, end, tid, wave, lane, wmin, wmax);
     if (DEPOSIT) {
         if (GROUPRED) flush_rows_group<2, T>(s_rows, ncp, C.rng, lds /* interp tables are dead by now */, tid, a);
         else flush_rows<2>(s_rows, ncp, C.rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
@@ -893,7 +915,7 @@ __global__ void __launch_bounds__(BLOCK) k_deposit_only(const StageArgsT<T> a)
     for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) C.rows[i] = 0.0;
     __syncthreads();
     const StageLds<T> L{nullptr, nullptr, C.xg, C.gs, C.rows};
-    deposit_pass<T, FVEC, 2>(a, L, start, end, tid, wave, lane);
+    deposit_pass<T, FVEC>(a, L, start, end, tid, wave, lane);
     flush_rows_group<2, T>(C.rows, ncp, C.rng, lds, tid, a);
 }
 
@@ -1053,7 +1075,8 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
     for (int i = tid; i < WAVES * NP * ncp; i += BLOCK) s_rows[i] = 0.0;
     __syncthreads();
     int wmin = INT_MAX, wmax = INT_MIN;
-    double acc0[NP][1] = {};                                 // unused (NH = 0: LDS accumulation)
+    DepWindow win;
+    win.clear();
     const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = (tile0 + t) * (long long)TILE;
@@ -1115,9 +1138,10 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
             if (NP == 2) { pay[0][r] = cgr * kk[r] * dens[r]; pay[NP - 1][r] = cgr * ll[r] * dens[r]; }   // :148-149
             else pay[0][r] = (a.var == 1) ? cgr * dens[r] : dens[r];                     // :167, :184
         }
-        deposit_tile<NP, 0, T>(lo, up, nlo, nup, vol, pay, s_G, a.dz, a.cdz, a.mk_ok,
-                               s_rows + wave * NP * ncp, ncp, lane, wmin, wmax, acc0);
+        deposit_tile<NP, T>(lo, up, nlo, nup, vol, pay, s_G, a.dz, a.cdz, a.mk_ok,
+                            s_rows + wave * NP * ncp, ncp, lane, wmin, wmax, win);
     }
+    if (NP == 2) flush_window(win, s_rows + wave * NP * ncp, ncp, lane);
     flush_rows<NP>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
 }
 
