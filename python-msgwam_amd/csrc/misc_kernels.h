@@ -100,19 +100,18 @@ __global__ void __launch_bounds__(BLOCK) k_xch_selftest(const XchTestArgs t)
     __shared__ int s_flag[4];
     const int tid = threadIdx.x;
     const XchArgs x = t.x;
-    const int ncols = min(x.stride, BLOCK);
+    const int ncols = x.stride;                                // the whole row (taller than one workgroup: strided)
     int good = 1;
     for (int round = 1; round <= t.rounds; ++round) {
-        double tot = 0.0;
         if (!xch_allsum(x, x.seq + (u64_t)round, nullptr, ncols, tid, s_flag + (round & 1),
-                        xch_test_value(x.rank, round, tid), tot)) {
+                        [&](int col) { return xch_test_value(x.rank, round, col); },
+                        [&](int col, double tot) {
+                            double want = 0.0;
+                            for (int r = 0; r < x.nranks; ++r) want = want + xch_test_value(r, round, col);
+                            if (tot != want) good = 0;
+                        })) {
             good = 0;
             break;
-        }
-        if (tid < ncols) {
-            double want = 0.0;
-            for (int r = 0; r < x.nranks; ++r) want = want + xch_test_value(r, round, tid);
-            if (tot != want) good = 0;
         }
     }
     const int all_good = __syncthreads_and(good);

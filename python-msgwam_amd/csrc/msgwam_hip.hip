@@ -646,6 +646,11 @@ int plan_persist(msgw_ctx *c, int nres, int mode, bool rl, bool multi, PersistPl
         // measured with 2 resident tiles: +10 % at 2e6 rays (8 tiles per workgroup), +3 % at 4e6 and 8e6 (16, 32),
         // -10 % at 16e6 (64), where 4 workgroups per CU with all rays streamed are better
         if (pl.tiles_per_block > 16 * nres) return MSGW_OK;
+    } else if (blocks + PERSIST_GROUPS + 2 > slots) {
+        // tall columns: the LDS footprint leaves fewer than the default 4 workgroups per CU
+        const long long maxb = slots - (PERSIST_GROUPS + 2);
+        if (maxb < 1) return MSGW_OK;
+        split_rays(c, c->n, maxb, &pl.rays_per_block, &pl.tiles_per_block, &blocks);
     }
     pl.blocks = blocks;
     const int max_groups = nres > 0 ? 16 : PERSIST_GROUPS;
@@ -668,7 +673,9 @@ template <typename T>
 int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_kernels, bool *used)
 {
     *used = false;
-    const bool can_fuse = (2 * (c->ng - 2) <= BLOCK) && (c->ng - 1 <= BLOCK);
+    // any column whose tables, wave rows and replica fit the LDS of a CU (ngrid <= ~870; up to 130 levels a thread of
+    // the reducer / column / exchange workgroups owns one column entry, beyond that it strides)
+    const bool can_fuse = persist_lds_bytes(c) <= 160 * 1024;
     const bool multi = c->nranks > 1 || c->force_coll;
     if ((flags & MSGW_FIXED_BACKGROUND) || count <= 0) return MSGW_OK;
     const int mode = c->sat_online ? 1 : ((flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 2 : 0);

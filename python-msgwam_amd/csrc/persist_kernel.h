@@ -159,17 +159,21 @@ __device__ __forceinline__ bool xch_wait_all(const u64_t *flags, int nranks, u64
     return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
 }
 
-// Node-level sum of one row per rank (see XchArgs).  `mine` is this rank's value of column `tid`; returns false after
-// a time-out.  s_flag: an LDS word not used by other hand-offs.
+// Node-level sum of one row per rank (see XchArgs).  `mine(col)` is this rank's value of column `col`, `sink(col, tot)`
+// receives the sum over the ranks (thread tid handles columns tid, tid + BLOCK, ...: columns taller than one workgroup);
+// returns false after a time-out.  s_flag: an LDS word not used by other hand-offs.
+template <typename Mine, typename Sink>
 __device__ __forceinline__ bool xch_allsum(const XchArgs x, u64_t seq, int *status, int ncols, int tid, int *s_flag,
-                                           double mine, double &tot)
+                                           Mine mine, Sink sink)
 {
     const size_t slot_off = (size_t)(seq & 1ull) * x.nranks * x.stride;
-    if (x.direct) {                                           // my row into the slot I own in every rank's buffer
-        if (tid < ncols)
-            for (int j = 0; j < x.nranks; ++j) st_sys(x.peer_rows[j] + slot_off + (size_t)x.rank * x.stride + tid, mine);
-    } else {
-        if (tid < ncols) st_sys(x.rows + slot_off + (size_t)x.rank * x.stride + tid, mine);
+    for (int col = tid; col < ncols; col += BLOCK) {
+        const double m = mine(col);
+        if (x.direct) {                                       // my row into the slot I own in every rank's buffer
+            for (int j = 0; j < x.nranks; ++j) st_sys(x.peer_rows[j] + slot_off + (size_t)x.rank * x.stride + col, m);
+        } else {
+            st_sys(x.rows + slot_off + (size_t)x.rank * x.stride + col, m);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // system scope: every storing wave's row is out
     __syncthreads();
@@ -187,9 +191,11 @@ __device__ __forceinline__ bool xch_allsum(const XchArgs x, u64_t seq, int *stat
     }
     __syncthreads();
     if (!*s_flag) return false;
-    tot = 0.0;
-    if (tid < ncols)
-        for (int r = 0; r < x.nranks; ++r) tot = tot + ld_sys(x.rows + slot_off + (size_t)r * x.stride + tid);   // rank order
+    for (int col = tid; col < ncols; col += BLOCK) {
+        double tot = 0.0;
+        for (int r = 0; r < x.nranks; ++r) tot = tot + ld_sys(x.rows + slot_off + (size_t)r * x.stride + col);   // rank order
+        sink(col, tot);
+    }
     return true;
 }
 
@@ -253,8 +259,8 @@ __device__ __forceinline__ void persist_reduce_group(const PersistArgsT<T> p, in
     const unsigned int par = f & 1u;
     const double *part = p.grp_part2 + (size_t)par * nb * a.row_stride;
     double *grow = p.grp_rows2 + ((size_t)par * PERSIST_GROUPS + g) * ncols;
-    if (tid < ncols) {
-        const double *src = part + tid;
+    for (int col = tid; col < ncols; col += BLOCK) {          // (one trip up to 130 levels)
+        const double *src = part + col;
         double acc = 0.0;
         for (int r = r0; r < r1; r += 32) {                   // row order, 32 loads in flight
             double v[32];
@@ -263,19 +269,19 @@ __device__ __forceinline__ void persist_reduce_group(const PersistArgsT<T> p, in
 #pragma unroll
             for (int u = 0; u < 32; ++u) acc = acc + ((r + u < r1) ? v[u] : 0.0);
         }
-        st_agent(grow + tid, acc);
+        st_agent(grow + col, acc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
-// Third level: the sum of the group sums of flux f, in group order (thread `tid` < ncols: its column).
-template <typename T>
-__device__ __forceinline__ double persist_sum_groups(const PersistArgsT<T> p, unsigned int f, int ncols, int tid)
+// Third level: the sum of the group sums of flux f, in group order; `sink(col, tot)` receives column `col`.
+template <typename T, typename Sink>
+__device__ __forceinline__ void persist_sum_groups(const PersistArgsT<T> p, unsigned int f, int ncols, int tid, Sink sink)
 {
-    double tot = 0.0;
-    if (tid < ncols) {
-        const double *src = p.grp_rows2 + (size_t)(f & 1u) * PERSIST_GROUPS * ncols + tid;
+    for (int col = tid; col < ncols; col += BLOCK) {
+        double tot = 0.0;
+        const double *src = p.grp_rows2 + (size_t)(f & 1u) * PERSIST_GROUPS * ncols + col;
         for (int r = 0; r < p.ngroups; r += 32) {
             double v[32];
 #pragma unroll
@@ -283,8 +289,8 @@ __device__ __forceinline__ double persist_sum_groups(const PersistArgsT<T> p, un
 #pragma unroll
             for (int u = 0; u < 32; ++u) tot = tot + ((r + u < p.ngroups) ? v[u] : 0.0);
         }
+        sink(col, tot);
     }
-    return tot;
 }
 
 // Without reducer workgroups: the last arriver of the flux's last group forms ONE final row (so that every
@@ -293,10 +299,9 @@ template <typename T>
 __device__ __forceinline__ void persist_reduce_final(const PersistArgsT<T> p, unsigned int f, int ncols, int tid)
 {
     const unsigned int par = f & 1u;
-    const double tot = persist_sum_groups(p, f, ncols, tid);
     // several ranks: this is only the rank's row; the exchange workgroup turns it into the final one
-    double *dst = p.xch ? p.flux2 + 2 * ncols : p.flux2;
-    if (tid < ncols) st_agent(dst + (size_t)par * ncols + tid, tot);
+    double *dst = (p.xch ? p.flux2 + 2 * ncols : p.flux2) + (size_t)par * ncols;
+    persist_sum_groups(p, f, ncols, tid, [&](int col, double tot) { st_agent(dst + col, tot); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -396,16 +401,16 @@ __device__ __forceinline__ void persist_service(const PersistArgsT<T> p, int g, 
     }
 }
 
-// Column / exchange workgroup: wait until all group sums of flux f are there, add them (registers),
+// Column / exchange workgroup: wait until all group sums of flux f are there, add them (`sink(col, tot)`, into LDS),
 // re-arm the counter.  Returns false after a time-out.
-template <typename T>
+template <typename T, typename Sink>
 __device__ __forceinline__ bool persist_take_groups(const PersistArgsT<T> p, unsigned int f, int ncols, int *s_flag,
-                                                    int tid, double &tot)
+                                                    int tid, Sink sink)
 {
     const unsigned int par = f & 1u;
     if (!persist_wait(p, (unsigned int)p.ngroups, s_flag, tid, p.done2 + par)) return false;
-    tot = persist_sum_groups(p, f, ncols, tid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the rows are in registers ...
+    persist_sum_groups(p, f, ncols, tid, sink);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the rows have been read ...
     __syncthreads();
     if (tid == 0) __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... re-arm for flux f+2
     return true;
@@ -421,18 +426,19 @@ __device__ __forceinline__ void persist_exchange(const PersistArgsT<T> p, int *s
     XchArgs x = *p.xch;
     x.seq = p.xch_seq;
     const double *flux_local = p.flux2 + 2 * ncols;
+    double *mine = reinterpret_cast<double *>(s_flag + 16);    // the rank's row, staged in LDS behind the flag words
     for (unsigned int f = 0; f < nflux; ++f) {
         const unsigned int par = f & 1u;
-        double mine = 0.0;
         if (p.nservice) {                                      // add the reducers' group sums: the rank's row
-            if (!persist_take_groups(p, f, ncols, s_flag + par, tid, mine)) return;
+            if (!persist_take_groups(p, f, ncols, s_flag + par, tid, [&](int col, double v) { mine[col] = v; })) return;
         } else {                                               // the last arriver has formed the rank's row
             if (!persist_wait(p, f + 1u, s_flag + par, tid, p.ready + PD_LOCAL)) return;
-            if (tid < ncols) mine = ld_agent(flux_local + (size_t)par * ncols + tid);
+            for (int col = tid; col < ncols; col += BLOCK) mine[col] = ld_agent(flux_local + (size_t)par * ncols + col);
         }
-        double tot = 0.0;
-        if (!xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, s_flag + 2 + par, mine, tot)) return;
-        if (tid < ncols) st_agent(p.flux2 + (size_t)par * ncols + tid, tot);
+        // (a thread only ever reads back the columns it staged itself: no barrier needed in between)
+        double *dst = p.flux2 + (size_t)par * ncols;
+        if (!xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, s_flag + 2 + par,
+                        [&](int col) { return mine[col]; }, [&](int col, double tot) { st_agent(dst + col, tot); })) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
@@ -464,28 +470,27 @@ __device__ __forceinline__ void persist_pack_tables(const PersistLds<T> L, int n
     }
 }
 
-// column_q = RK stage `pstage` of column_{q-1} with the final row of flux F_{q-1}; `have` = this thread's
-// value of the row (column `tid`) when the caller holds it in registers, else it is loaded from flux2
+// column_q = RK stage `pstage` of column_{q-1} with the final row of flux F_{q-1}: `in_lds` = the caller has already
+// put the row into L.F (pm_flux[:, 1:-1] at [p*ng + 1 + c]), else it is loaded from flux2
 template <typename T>
 __device__ __forceinline__ void persist_column(const PersistArgsT<T> p, const PersistLds<T> L, unsigned int q,
-                                               int pstage, int tid, bool in_regs = false, double have = 0.0)
+                                               int pstage, int tid, bool in_lds = false)
 {
     const StageArgsT<T> a = p.s;
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2, ncols = 2 * ncp;
-    if (tid < ncols) {
-        const int pp = tid / ncp, c = tid - pp * ncp;
-        L.F[pp * ng + 1 + c] = in_regs ? have                  // pm_flux[:, 1:-1] (:654)
-                                       : ld_agent(p.flux2 + (size_t)((q - 1) & 1) * ncols + tid);
-    }
+    if (!in_lds)
+        for (int col = tid; col < ncols; col += BLOCK) {
+            const int pp = col / ncp, c = col - pp * ncp;
+            L.F[pp * ng + 1 + c] = ld_agent(p.flux2 + (size_t)((q - 1) & 1) * ncols + col);   // pm_flux[:, 1:-1] (:654)
+        }
     __syncthreads();
     column_flux_ends(tid, ng, L.F);
     __syncthreads();
-    if (tid < nc) {
+    for (int j = tid; j < nc; j += BLOCK) {
         double du, dv, un, vn, qu, qv;
-        column_tendency(tid, ng, a.f0, a.dzg, 0, L.F, L.crho[tid], L.cpg[tid], L.cpg[nc + tid], L.cu[tid],
-                        L.cv[tid], du, dv);
-        column_rk(pstage, a.dtc, du, dv, L.cu[tid], L.cv[tid], L.cqu[tid], L.cqv[tid], un, vn, qu, qv);
-        L.cu[tid] = un; L.cv[tid] = vn; L.cqu[tid] = qu; L.cqv[tid] = qv;
+        column_tendency(j, ng, a.f0, a.dzg, 0, L.F, L.crho[j], L.cpg[j], L.cpg[nc + j], L.cu[j], L.cv[j], du, dv);
+        column_rk(pstage, a.dtc, du, dv, L.cu[j], L.cv[j], L.cqu[j], L.cqv[j], un, vn, qu, qv);
+        L.cu[j] = un; L.cv[j] = vn; L.cqu[j] = qu; L.cqv[j] = qv;
     }
     __syncthreads();
     column_shear(tid, BLOCK, ng, a.dzg, L.cu, L.cv, L.du, L.dv);
@@ -511,9 +516,12 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgsT<T> p, const
             if (!persist_wait(p, f + 1u, L.flag, tid, p.ready + PD_ROW)) return;
             persist_column(p, L, f + 1u, (int)(f % 3u), tid);
         } else {                                               // one rank: add the reducers' group sums right here
-            double tot = 0.0;
-            if (!persist_take_groups(p, f, ncols, L.flag, tid, tot)) return;
-            persist_column(p, L, f + 1u, (int)(f % 3u), tid, true, tot);
+            const int ncp = ng - 2;
+            if (!persist_take_groups(p, f, ncols, L.flag, tid, [&](int col, double tot) {
+                    const int pp = col / ncp, c = col - pp * ncp;
+                    L.F[pp * ng + 1 + c] = tot;                // pm_flux[:, 1:-1] (:654)
+                })) return;
+            persist_column(p, L, f + 1u, (int)(f % 3u), tid, true);
         }
         double *tab = p.shtab + (size_t)(f & 1u) * 4 * ni;
         const double *src = reinterpret_cast<const double *>(L.shd);

@@ -306,11 +306,9 @@ def test_full_size_config2_fixed_background_1000_steps():
     assert np.array_equal(one[9], st[9]) and np.array_equal(one[10], st[10])
 
 
-def test_tall_column_path_vs_c_oracle():
-    """ngrid = 301 (> 130 levels): per-level sums stay in LDS, standalone column kernel per stage."""
-    rng = np.random.default_rng(77)
-    n = 30_011
-    grid = np.linspace(0, 150e3, 301)
+def _tall_case(ngrid, n, seed=77):
+    rng = np.random.default_rng(seed)
+    grid = np.linspace(0, 150e3, ngrid)
     area = rng.uniform(1e-3, 1e-1, n)
     s = orc.Setup(grid, phi0=0.2, kappa=0.9, saturate_online=False, dkk=np.full(n, 1e-4), dll=np.full(n, 1e-4),
                   rr_mm_area=area)
@@ -323,11 +321,44 @@ def test_tall_column_path_vs_c_oracle():
     # amplifies summation-order noise x500 per step (3.7e-14 -> 9e-10 in three steps)
     st = [rng.uniform(0, 1e7, n), np.zeros(n), np.full(n, 0.2), rr, drr, rng.normal(0, 1e-4, n),
           rng.normal(0, 1e-4, n), rng.normal(0, 2e-3, n), area / drr, uu, vv]
+    return s, st
+
+
+@pytest.mark.parametrize("ngrid,env,persist", [(301, {}, True), (301, {"MSGW_REGTILES": "0"}, True),
+                                               (301, {"MSGW_PERSIST": "0"}, False), (131, {}, True),
+                                               (600, {}, True), (600, {"MSGW_SERVICE": "0"}, True)])
+def test_tall_column_path_vs_c_oracle(monkeypatch, ngrid, env, persist):
+    """More than 130 levels: the threads of the reducer / column / exchange workgroups of the persistent kernel stride
+    over the column entries (one each up to 130 levels); as a launch chain the per-level sums stay in LDS and a
+    standalone column kernel runs per stage."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s, st = _tall_case(ngrid, 30_011)
     want = COracle(s).step(60.0, 3, st)
     p = make_prop(s, st)
     p.step(60.0, 3)
     check_state(gpu_state(p, st), want, 1e-10, 1e-11, "tall")
+    assert p.counters()["persist_steps"] == (3 if persist else 0)
     p.close()
+
+
+def test_tall_column_through_the_one_rank_exchange(monkeypatch):
+    """ngrid = 301 through the exchange workgroup (rows wider than one workgroup) == without it, bit for bit."""
+    s, st = _tall_case(301, 20_003, seed=5)
+    p = make_prop(s, st)
+    p.step(60.0, 4)
+    ref = gpu_state(p, st)
+    p.close()
+    monkeypatch.setenv("MSGW_FORCE_COLLECTIVE", "1")
+    p = make_prop(s, st)
+    p.comm_init(_capi.comm_unique_id(), 0, 1)
+    assert p.counters()["exchange"] == 1
+    p.step(60.0, 4)
+    got = gpu_state(p, st)
+    assert p.counters()["persist_steps"] == 4
+    p.close()
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
 
 
 def test_collective_chain_with_one_rank_communicator(monkeypatch):
