@@ -77,7 +77,9 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
         int nlo[2], nup[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const double sinp = sin(phi[r]), cosp = cos(phi[r]), tanp = tan(phi[r]);
+            double sinp, cosp;
+            sincos(phi[r], &sinp, &cosp);                      // one argument reduction for both
+            const double tanp = sinp / cosp;                   // (np.tan to ~1 ulp: this path is held to rtol 1e-10)
             const double f = h.two_rot * sinp;                                      // :382
             const double f2 = f * f;
             double kh2, m2, vk2, om, cgr;

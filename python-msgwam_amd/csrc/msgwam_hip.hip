@@ -292,7 +292,10 @@ int ensure_lds(msgw_ctx *c, const void *kernel, size_t bytes)
 //  * ranges of whole WAVE quanta (a quarter tile) with wavefronts skipping the empty part of a workgroup's last
 //    tile, so that 1.25e6 float32 rays make 1024 workgroups of ~1.2 tiles instead of 611 of two: 59 -> 71 us per
 //    step with all rays streamed, 113 -> 129 us for the launch chain (more workgroups to synchronise, and a lone
-//    wavefront in a partly empty tile has nothing to hide its latency behind).
+//    wavefront in a partly empty tile has nothing to hide its latency behind).  The same for the resident flavour
+//    only, with the number of workgroups unchanged (494 ranges of 2.5 instead of 407 of 3 float32 tiles, idle
+//    wavefronts skipping the tile body): no gain either (config 5 59.2 vs 58.5, 1.2e6 float64 rays 55.1 vs 55.0 us):
+//    a pass lasts as long as a wavefront's serial chain over its tiles, not as the CU's summed work.
 void split_rays(const msgw_ctx *c, int64_t n, int64_t maxb, int64_t *rays_per_block, int *tiles_per_block, int *blocks)
 {
     const int64_t ntiles = (n + c->tile - 1) / c->tile;
@@ -658,9 +661,10 @@ int plan_persist(msgw_ctx *c, int nres, int mode, bool rl, bool multi, PersistPl
     pl.ngroups = (blocks + pl.grp_size - 1) / pl.grp_size;
     // reducer workgroups (one per group) + the column workgroup when they fit beside the ray workgroups,
     // else the last arriver reduces
-    pl.nservice = (c->service && blocks + pl.ngroups + 1 + (multi ? 1 : 0) <= slots) ? pl.ngroups : 0;
-    // + reducer workgroups + the column workgroup + the exchange workgroup
-    pl.grid = blocks + pl.nservice + (pl.nservice ? 1 : 0) + (multi ? 1 : 0);
+    pl.nservice = (c->service && blocks + pl.ngroups + 1 <= slots) ? pl.ngroups : 0;
+    // + reducer workgroups + the column workgroup (which also sums over the ranks); without them, several ranks:
+    // + one exchange workgroup
+    pl.grid = blocks + pl.nservice + (pl.nservice ? 1 : 0) + ((multi && !pl.nservice) ? 1 : 0);
     *fits = slots >= pl.grid && pl.grid <= 2048;               // every workgroup co-resident
     return MSGW_OK;
 }
@@ -738,7 +742,7 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     c->status_armed = true;
     c->cnt.persist_resident_tiles = pl.nres;
     c->cnt.persist_steps = count;
-    if (multi) c->xch_seq += 3ull * (unsigned long long)count + 1ull;   // fluxes 0 .. 3*count were exchanged
+    if (multi) c->xch_seq += 3ull * (unsigned long long)count;   // fluxes 0 .. 3*count-1 were exchanged (strictly alternating slots)
     return MSGW_OK;
 }
 
@@ -1464,7 +1468,9 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
     const bool time_kernels = (flags & MSGW_TIME_KERNELS) != 0;
     // With a real collective in the chain launches stay eager: hipGraph capture of ncclAllReduce
     // across ranks cannot be exercised on the 1-GPU development boxes, so it is not relied upon.
-    const bool eager = time_kernels || (flags & MSGW_NO_GRAPH) || c->graph_steps == 0 || c->nranks > 1 ||
+    // (measured with a 1-rank communicator: replaying the captured two-stream chain is slower than launching it
+    // eagerly, 146 vs 120 us per step)
+    const bool eager = time_kernels || (flags & MSGW_NO_GRAPH) || c->graph_steps == 0 || c->nranks > 1 || c->force_coll ||
                        (flags & MSGW_FIXED_BACKGROUND);      // fixed background: one launch for all steps anyway
     const unsigned gflags = flags & ~(MSGW_NO_GRAPH | MSGW_TIME_KERNELS);
     if (time_kernels) c->kev_used = 0;

@@ -46,7 +46,7 @@ namespace msgw {
 
 constexpr unsigned int PERSIST_OPT_PRIO = 1u;   // workgroups that trail by a pass run it at raised wave priority
 constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
-constexpr int PD_ROW = 64;               // ready[PD_ROW]: fluxes whose final row is in flux2 (own cache line)
+constexpr int PD_ROW = 64;               // (unused since the column workgroup does the sum over the ranks itself)
 constexpr int PD_LOCAL = 96;             // ready[PD_LOCAL]: several ranks: fluxes whose rank row is complete
 constexpr int TICKET_STRIDE = 32;        // unsigned ints between two tickets: pollers and arrivers of different
                                          // groups never share a cache line
@@ -422,27 +422,23 @@ template <typename T>
 __device__ __forceinline__ void persist_exchange(const PersistArgsT<T> p, int *s_flag, int tid)
 {
     const int ncols = 2 * (p.s.ng - 2);
-    const unsigned int nflux = 3u * (unsigned int)p.nsteps + 1u;
+    const unsigned int nflux = 3u * (unsigned int)p.nsteps;      // the flux of the final state is not needed by anybody
     XchArgs x = *p.xch;
     x.seq = p.xch_seq;
     const double *flux_local = p.flux2 + 2 * ncols;
     double *mine = reinterpret_cast<double *>(s_flag + 16);    // the rank's row, staged in LDS behind the flag words
     for (unsigned int f = 0; f < nflux; ++f) {
         const unsigned int par = f & 1u;
-        if (p.nservice) {                                      // add the reducers' group sums: the rank's row
-            if (!persist_take_groups(p, f, ncols, s_flag + par, tid, [&](int col, double v) { mine[col] = v; })) return;
-        } else {                                               // the last arriver has formed the rank's row
-            if (!persist_wait(p, f + 1u, s_flag + par, tid, p.ready + PD_LOCAL)) return;
-            for (int col = tid; col < ncols; col += BLOCK) mine[col] = ld_agent(flux_local + (size_t)par * ncols + col);
-        }
+        // (no reducer workgroups: the last arriver has formed the rank's row)
+        if (!persist_wait(p, f + 1u, s_flag + par, tid, p.ready + PD_LOCAL)) return;
+        for (int col = tid; col < ncols; col += BLOCK) mine[col] = ld_agent(flux_local + (size_t)par * ncols + col);
         // (a thread only ever reads back the columns it staged itself: no barrier needed in between)
         double *dst = p.flux2 + (size_t)par * ncols;
         if (!xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, s_flag + 2 + par,
                         [&](int col) { return mine[col]; }, [&](int col, double tot) { st_agent(dst + col, tot); })) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0)
-            __hip_atomic_fetch_add(p.nservice ? p.ready + PD_ROW : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -510,19 +506,20 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgsT<T> p, const
     const int ng = p.s.ng, ni = ng - 2, nc = ng - 1;
     const unsigned int nflux = 3u * (unsigned int)p.nsteps;      // the flux of the final state is unused
     const int ncols = 2 * (ng - 2);
+    const int ncp = ng - 2;
+    auto slot = [&](int col) { const int pp = col / ncp; return pp * ng + 1 + (col - pp * ncp); };   // pm_flux[:, 1:-1] (:654)
+    XchArgs x{};
+    if (p.xch) { x = *p.xch; x.seq = p.xch_seq; }
     for (unsigned int f = 0; f < nflux; ++f) {
-        // pass q = f+1 is RK stage q % 3, column stage (q+2) % 3 = f % 3
-        if (p.xch) {                                       // several ranks: the exchange workgroup's final row
-            if (!persist_wait(p, f + 1u, L.flag, tid, p.ready + PD_ROW)) return;
-            persist_column(p, L, f + 1u, (int)(f % 3u), tid);
-        } else {                                               // one rank: add the reducers' group sums right here
-            const int ncp = ng - 2;
-            if (!persist_take_groups(p, f, ncols, L.flag, tid, [&](int col, double tot) {
-                    const int pp = col / ncp, c = col - pp * ncp;
-                    L.F[pp * ng + 1 + c] = tot;                // pm_flux[:, 1:-1] (:654)
-                })) return;
-            persist_column(p, L, f + 1u, (int)(f % 3u), tid, true);
-        }
+        // pass q = f+1 is RK stage q % 3, column stage (q+2) % 3 = f % 3.  Add the reducers' group sums right here
+        // (into L.F); several ranks: that is this rank's row, and the sum over the ranks follows at once (a
+        // separate exchange workgroup cost one more hand-off per flux on the critical reduce chain: 46.7 vs 45.0 us
+        // per step with a 1-rank communicator)
+        if (!persist_take_groups(p, f, ncols, L.flag, tid, [&](int col, double tot) { L.F[slot(col)] = tot; })) return;
+        if (p.xch && !xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, L.flag + 4 + (f & 1u),
+                                 [&](int col) { return L.F[slot(col)]; },
+                                 [&](int col, double tot) { L.F[slot(col)] = tot; })) return;
+        persist_column(p, L, f + 1u, (int)(f % 3u), tid, true);
         double *tab = p.shtab + (size_t)(f & 1u) * 4 * ni;
         const double *src = reinterpret_cast<const double *>(L.shd);
         for (int i = tid; i < 4 * ni; i += BLOCK) st_agent(tab + i, src[i]);
@@ -623,8 +620,8 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
     if (role >= 0) {
         __builtin_amdgcn_s_setprio(3);                         // they only ever poll and reduce: react at once
         if (role < p.nservice) { persist_service(p, role, reinterpret_cast<int *>(lds), tid); return; }
-        if (role > p.nservice || !p.nservice) { persist_exchange(p, reinterpret_cast<int *>(lds), tid); return; }
-    }                                                          // role == nservice > 0: the column workgroup, below
+        if (!p.nservice) { persist_exchange(p, reinterpret_cast<int *>(lds), tid); return; }   // (several ranks, no reducers)
+    }                                                          // role == nservice > 0: the column (+ exchange) workgroup, below
     const long long start = (long long)blockIdx.x * a.rays_per_block;
     const long long end = min(a.n, start + a.rays_per_block);
     // (Wave priority by dispatch round, youngest highest, was measured: it inverts which workgroup of
