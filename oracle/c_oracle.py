@@ -37,6 +37,7 @@ def lib():
         build()
         _lib = C.CDLL(LIB)
         _lib.orc_step.restype = C.c_int
+        _lib.orc_step_nz.restype = C.c_int
     return _lib
 
 
@@ -54,7 +55,9 @@ class COracle:
     def __init__(self, setup, fixed_background=False):
         self.grid, self.grids = _c(setup.grid), _c(setup.grids)
         self.rhobar, self.pg = _c(setup.rhobar), _c(setup.pressure_gradient)
-        self.bvf = float(setup.bvf)
+        # EXTENSION: bvf as a column on grids -> orc_step_nz / orc_rhs_nz (drr, dmm evolve)
+        self.bvfcol = _c(setup.bvf) if np.ndim(setup.bvf) else None
+        self.bvf = float("nan") if self.bvfcol is not None else float(setup.bvf)
         self.s = _Setup(len(self.grid), _p(self.grid), _p(self.grids), _p(self.rhobar), _p(self.pg),
                         self.bvf, float(2 * ROT_EARTH * np.sin(setup.phi0)), float(setup.kappa),
                         int(bool(setup.saturate_online)), int(fixed_background))
@@ -68,6 +71,15 @@ class COracle:
         """state = 11-slot list; returns a new list (lam, phi, drr, kk, ll, dmm unchanged)."""
         dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = [_c(a).copy() for a in state]
         fr = self.fray(phi)
+        if self.bvfcol is not None:
+            if direct_sat:
+                raise NotImplementedError("the N(z) column extension has no direct saturation")
+            rc = lib().orc_step_nz(C.byref(self.s), _p(self.bvfcol), C.c_double(dt), C.c_int(nsteps),
+                                   C.c_int64(len(dens)), _p(dens), _p(rr), _p(drr), _p(kk), _p(ll), _p(mm),
+                                   _p(dmm), _p(fr), _p(self.dkk), _p(self.dll), _p(self.area), _p(uu), _p(vv))
+            if rc:
+                raise MemoryError("orc_step_nz")
+            return [dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv]
         rc = lib().orc_step(C.byref(self.s), C.c_double(dt), C.c_int(nsteps), C.c_int(direct_sat),
                             C.c_int64(len(dens)), _p(dens), _p(rr), _p(drr), _p(kk), _p(ll), _p(mm),
                             _p(dmm), _p(fr), _p(self.dkk), _p(self.dll), _p(self.area), _p(uu), _p(vv))
@@ -81,6 +93,12 @@ class COracle:
         fr = self.fray(phi)
         sd, sr, sm = np.empty(n), np.empty(n), np.empty(n)
         du, dv, flux = np.empty(nc), np.empty(nc), np.empty((2, nc + 1))
+        if self.bvfcol is not None:
+            sdr, sdm = np.empty(n), np.empty(n)
+            lib().orc_rhs_nz(C.byref(self.s), _p(self.bvfcol), C.c_double(dt), C.c_int64(n), _p(dens), _p(rr),
+                             _p(drr), _p(kk), _p(ll), _p(mm), _p(dmm), _p(fr), _p(self.dkk), _p(self.dll),
+                             _p(self.area), _p(uu), _p(vv), _p(sd), _p(sr), _p(sdr), _p(sm), _p(sdm), _p(du), _p(dv))
+            return dict(dens=sd, rr=sr, drr=sdr, mm=sm, dmm=sdm, uu=du, vv=dv)
         lib().orc_rhs(C.byref(self.s), C.c_double(dt), C.c_int64(n), _p(dens), _p(rr), _p(drr), _p(kk),
                       _p(ll), _p(mm), _p(dmm), _p(fr), _p(self.dkk), _p(self.dll), _p(self.area),
                       _p(uu), _p(vv), _p(sd), _p(sr), _p(sm), _p(du), _p(dv), _p(flux))

@@ -2,7 +2,8 @@
  * ORACLE -- test infrastructure, NOT the product.
  *
  * Plain-C, single-thread restatement of python-msgwam's ray-propagation hot
- * path (HPROP_GLOBAL = False branch, scalar bvf), written from the reference's
+ * path (HPROP_GLOBAL = False branch; scalar bvf, plus the build-defined N(z)
+ * column extension at the end of the file), written from the reference's
  * algorithm, operation by operation in numpy's evaluation order, so that with
  * -ffp-contract=off it is bit-comparable with the reference.  It exists so the
  * GPU parity tests can check 1e5..1e6-ray cases in seconds.  It is validated
@@ -281,5 +282,140 @@ int orc_step(const orc_setup *s, double dt, int nsteps, int direct_sat, int64_t 
                             mo, mm, dkk, dll, area);
     }
     free(sd); free(sr); free(sm); free(qd); free(qr); free(qm); free(ro); free(mo); free(du);
+    return 0;
+}
+
+/* ======================================================================================================
+ * EXTENSION, no reference behaviour: buoyancy frequency as a column N on `grids`.
+ * C restatement of the definition in oracle/msgwam_oracle.py (bvf_at, bvf_gradient_at, rhs, saturation),
+ * operation by operation, so that it agrees with it bit for bit (tests/test_oracle_c.py); with a constant
+ * column every expression reduces to the reference's, which is what pins this code path.
+ * Five evolving per-ray slots: dens, rr, drr, mm, dmm (lib/libprop.py:640-645 with cgr_up != cgr_down).
+ * ====================================================================================================== */
+
+/* slope of the np.interp segment grids[j] <= z < grids[j+1]; 0 where np.interp clamps; NaN stays NaN */
+static double bvf_slope_at_(const double *g, const double *b, int n, double z)
+{
+    if (isnan(z)) return z;
+    if (!(z >= g[0] && z < g[n - 1])) return 0.0;
+    int lo = 0, hi = n - 1;                 /* searchsorted(g, z, 'right') - 1, clipped to [0, n-2] */
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (z >= g[mid]) lo = mid; else hi = mid;
+    }
+    if (lo > n - 2) lo = n - 2;
+    return (b[lo + 1] - b[lo]) / (g[lo + 1] - g[lo]);
+}
+
+void orc_rhs_nz(const orc_setup *s, const double *bvfcol, double dt, int64_t n,
+                const double *dens, const double *rr, const double *drr, const double *kk,
+                const double *ll, const double *mm, const double *dmm, const double *fray,
+                const double *dkk, const double *dll, const double *area,
+                const double *uu, const double *vv,
+                double *st_dens, double *st_rr, double *st_drr, double *st_mm, double *st_dmm,
+                double *du, double *dv)
+{
+    int ng = s->ngrid, nc = ng - 1, ni = ng - 2;
+    double dz = s->grid[1] - s->grid[0];
+    double *dudz = (double *)malloc(sizeof(double) * (size_t)ni * 2);
+    double *dvdz = dudz + ni;
+    for (int j = 0; j < ni; ++j) {
+        dudz[j] = (uu[j + 1] - uu[j]) / dz;
+        dvdz[j] = (vv[j + 1] - vv[j]) / dz;
+    }
+    double *P = (double *)calloc((size_t)2 * (nc - 1), sizeof(double));
+    double *F = (double *)calloc((size_t)2 * ng, sizeof(double));
+    const double *xp = s->grid + 1;
+    for (int64_t i = 0; i < n; ++i) {
+        double ff = fray[i];
+        double bvf = np_interp1(rr[i], s->grids, bvfcol, nc);                       /* N at the ray */
+        double cgr_up = cg_rr_(kk[i], ll[i], mm[i], ff, np_interp1(rr[i] + .5 * drr[i], s->grids, bvfcol, nc));   /* :635 */
+        double cgr_down = cg_rr_(kk[i], ll[i], mm[i], ff, np_interp1(rr[i] - .5 * drr[i], s->grids, bvfcol, nc)); /* :636 */
+        double gu = np_interp1(rr[i], xp, dudz, ni);
+        double gv = np_interp1(rr[i], xp, dvdz, ni);
+        double gradient = kk[i] * gu + ll[i] * gv;                                  /* :517 */
+        gradient = gradient + (bvf * (kk[i] * kk[i] + ll[i] * ll[i]) / omega_(kk[i], ll[i], mm[i], ff, bvf)
+                               / (kk[i] * kk[i] + ll[i] * ll[i] + mm[i] * mm[i])
+                               * bvf_slope_at_(s->grids, bvfcol, nc, rr[i]));       /* refraction by dN/dz */
+        double dmm_st = (kk[i] * 0.0 + ll[i] * 0.0) / (RAD_EARTH + rr[i]) - gradient;
+        double drr_st = .5 * (cgr_down + cgr_up);                                   /* :640 */
+        double ddrr_st = cgr_up - cgr_down;                                         /* :641 */
+        double ddmm_st = dmm[i] / drr[i] * ddrr_st;                                 /* :645 */
+        st_rr[i] = drr_st; st_drr[i] = ddrr_st; st_mm[i] = dmm_st; st_dmm[i] = ddmm_st;
+        double rr_final = rr[i] + drr_st * dt;
+        double drr_final = drr[i] + ddrr_st * dt;
+        double mm_final = mm[i] + dmm_st * dt;
+        double dmm_final = area[i] / drr_final;
+        double rho_f = np_interp1(rr_final, s->grids, s->rhobar, nc);
+        double NN = np_interp1(rr_final, s->grids, bvfcol, nc);                     /* N at the projected height */
+        double omh = omega_(kk[i], ll[i], mm[i], s->f0, bvf);
+        double pv = dkk[i] * dll[i] * dmm_final;
+        double maxd = s->kappa * s->kappa * .5 * rho_f * omh * (NN * NN)
+                      / (mm_final * mm_final) / (omh * omh - s->f0 * s->f0);
+        double dst = 0.0;
+        if (maxd < dens[i] * pv) dst = (maxd - dens[i]) / dt;
+        st_dens[i] = (double)s->saturate_online * dst;
+        double lo = rr[i] - .5 * drr[i], up = rr[i] + .5 * drr[i];
+        double mlo = mm[i] - .5 * dmm[i], mup = mm[i] + .5 * dmm[i];
+        double vol = fabs(dkk[i] * dll[i] * dmm[i]);
+        project_ray(dens[i], lo, up, kk[i], ll[i], .5 * (mlo + mup), ff, vol, bvf, s->grids, nc, 0, P);
+    }
+    int np_ = nc - 1;
+    for (int c = 0; c < 2; ++c) {
+        for (int j = 0; j < np_; ++j) F[c * ng + 1 + j] = P[c * np_ + j];
+        F[c * ng + 0] = F[c * ng + 1];
+        F[c * ng + ng - 1] = F[c * ng + ng - 2];
+    }
+    for (int j = 0; j < nc; ++j) {
+        double gx = (F[j + 1] - F[j]) / dz;
+        double gy = (F[ng + j + 1] - F[ng + j]) / dz;
+        double rinv = 1.0 / s->rhobar[j];
+        du[j] = s->f0 * vv[j] - rinv * (s->pg[j] + gx);
+        dv[j] = -s->f0 * uu[j] - rinv * (s->pg[nc + j] + gy);
+        if (s->fixed_background) { du[j] = 0.0; dv[j] = 0.0; }
+    }
+    free(dudz); free(P); free(F);
+}
+
+/* nsteps of RK3 with the N(z) column: dens, rr, drr, mm, dmm, uu, vv advanced in place */
+int orc_step_nz(const orc_setup *s, const double *bvfcol, double dt, int nsteps, int64_t n,
+                double *dens, double *rr, double *drr, const double *kk, const double *ll,
+                double *mm, double *dmm, const double *fray,
+                const double *dkk, const double *dll, const double *area,
+                double *uu, double *vv)
+{
+    int nc = s->ngrid - 1;
+    size_t nb = sizeof(double) * (size_t)(n ? n : 1);
+    double *st = malloc(nb * 5), *q = malloc(nb * 5);
+    double *du = malloc(sizeof(double) * nc * 4), *dv = du + nc, *qu = du + 2 * nc, *qv = du + 3 * nc;
+    if (!st || !q || !du) return -1;
+    const double A[3] = {0.0, 5.0 / 9.0, 153.0 / 128.0};
+    const double B23[3] = {0.0, 15.0 / 16.0, 8.0 / 15.0};
+    double *y[5] = {dens, rr, drr, mm, dmm};
+    for (int it = 0; it < nsteps; ++it) {
+        for (int sg = 0; sg < 3; ++sg) {
+            orc_rhs_nz(s, bvfcol, dt, n, dens, rr, drr, kk, ll, mm, dmm, fray, dkk, dll, area, uu, vv,
+                       st, st + n, st + 2 * n, st + 3 * n, st + 4 * n, du, dv);
+            for (int v = 0; v < 5; ++v) {
+                double *yy = y[v], *qq = q + (size_t)v * n; const double *ss = st + (size_t)v * n;
+                for (int64_t i = 0; i < n; ++i) {
+                    if (sg == 0) { qq[i] = dt * ss[i]; yy[i] = yy[i] + qq[i] / 3; }
+                    else { qq[i] = dt * ss[i] - A[sg] * qq[i]; yy[i] = yy[i] + B23[sg] * qq[i]; }
+                }
+            }
+            for (int j = 0; j < nc; ++j) {
+                if (sg == 0) {
+                    qu[j] = dt * du[j]; qv[j] = dt * dv[j];
+                    uu[j] = uu[j] + qu[j] / 3; vv[j] = vv[j] + qv[j] / 3;
+                } else {
+                    qu[j] = dt * du[j] - A[sg] * qu[j];
+                    qv[j] = dt * dv[j] - A[sg] * qv[j];
+                    uu[j] = uu[j] + B23[sg] * qu[j];
+                    vv[j] = vv[j] + B23[sg] * qv[j];
+                }
+            }
+        }
+    }
+    free(st); free(q); free(du);
     return 0;
 }

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import msgwam_oracle as orc
+from oracle.c_oracle import COracle
 from helpers import STATE_KEYS, load, setup_from, state_from, relerr
 from gpu_helpers import gpu_state
 from msgwam_amd import _capi
@@ -98,6 +99,23 @@ def test_height_dependent_column_vs_the_definition(n, seed, sat, phi_mode, sorte
     p.step(60.0, 2)
     got = gpu_state_nz(p, st)
     check_state(got, want, 1e-10, 1e-11, ("N(z)", n))
+    for i in (4, 8):
+        assert relerr(got[i], want[i]) <= 1e-10, STATE_KEYS[i]
+    p.close()
+
+
+def test_height_dependent_column_at_size_vs_c_oracle():
+    """3e5 rays, random N(z), online saturation, two calls: against the C restatement of the extension (which agrees
+    bit for bit with the numpy definition, tests/test_oracle_c.py)."""
+    s, st = _random_case(300_007, 47, True, "uniform", True)
+    col = _column(s.grids, 9)
+    s.bvf = col
+    want = COracle(s).step(60.0, 3, st)
+    p = make_prop_nz(s, st, col)
+    p.step(60.0, 1)
+    p.step(60.0, 2)
+    got = gpu_state_nz(p, st)
+    check_state(got, want, 1e-10, 1e-11, "N(z) 3e5")
     for i in (4, 8):
         assert relerr(got[i], want[i]) <= 1e-10, STATE_KEYS[i]
     p.close()

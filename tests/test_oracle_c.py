@@ -101,3 +101,48 @@ def test_c_matches_numpy_oracle_random():
     b = COracle(s).step(60.0, 1, st)
     for k, x, y in zip(STATE_KEYS, a, b):
         np.testing.assert_array_equal(x, y, err_msg=k)
+
+
+def _nz_case(n, seed, sat):
+    rng = np.random.default_rng(seed)
+    grid = np.linspace(0, 100e3, 101)
+    s = orc.Setup(grid, phi0=0.4, kappa=0.95, saturate_online=sat,
+                  dkk=np.full(n, 1e-4), dll=np.full(n, 1e-4), rr_mm_area=rng.uniform(1e-3, 1e-1, n))
+    uu = orc.velocities_sine_homogeneous(s.grids, 4.0, 40e3, 10e3)
+    vv = 0.3 * uu[::-1]
+    s.set_pressure_gradient(uu, vv)
+    rr = rng.uniform(-1e3, 105e3, n)
+    drr = rng.uniform(50, 4000, n)
+    kk, ll = rng.normal(0, 1e-4, n), rng.normal(0, 1e-4, n)
+    mm = rng.normal(0, 2e-3, n)
+    phi = rng.uniform(-0.5, 0.5, n)
+    st = [rng.uniform(0, 1e9, n), np.zeros(n), phi, rr, drr, kk, ll, mm, s.rr_mm_area / drr, uu, vv]
+    return s, st
+
+
+@pytest.mark.parametrize("sat", [False, True])
+def test_c_nz_column_matches_the_numpy_definition_bit_for_bit(sat):
+    """EXTENSION: the C restatement of the N(z) column == oracle/msgwam_oracle.py, which defines it:
+    one RHS (all tendencies incl. drr, dmm) and two RK3 steps, rays below ground / above the top included."""
+    s, st = _nz_case(2500, 11, sat)
+    s.bvf = 0.01 * (1 + 0.3 * np.sin(s.grids / 17e3 + 1.0) + 0.1 * s.grids / s.grids[-1])
+    t = orc.rhs(s, 60.0, st)
+    c = COracle(s).rhs(60.0, st)
+    for k, i in (("dens", 0), ("rr", 3), ("drr", 4), ("mm", 7), ("dmm", 8), ("uu", 9), ("vv", 10)):
+        np.testing.assert_array_equal(c[k], t[i], err_msg=k)
+    assert np.any(c["drr"] != 0.0)
+    a = orc.rk3(s, 60.0, orc.rk3(s, 60.0, st))
+    b = COracle(s).step(60.0, 2, st)
+    for k, x, y in zip(STATE_KEYS, a, b):
+        np.testing.assert_array_equal(x, y, err_msg=k)
+
+
+def test_c_nz_constant_column_is_the_reference_path():
+    """With N(z) = const the extension's code path gives the scalar (reference-pinned) path's results bit for bit
+    (drr, dmm stay put: cgr_up == cgr_down)."""
+    s, st = _nz_case(2000, 12, True)
+    want = COracle(s).step(60.0, 3, st)
+    s.bvf = np.full(len(s.grids), 0.01)
+    got = COracle(s).step(60.0, 3, st)
+    for k, x, y in zip(STATE_KEYS, want, got):
+        np.testing.assert_array_equal(x, y, err_msg=k)
