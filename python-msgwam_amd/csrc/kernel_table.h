@@ -44,7 +44,8 @@ const void *persist_kernel_impl(bool sat, bool fvec, bool direct, bool relaunch)
 template <typename T>
 inline const void *persist_kernel(bool sat, bool fvec, bool direct, int nres, bool relaunch)
 {
-    return nres > 0 ? persist_kernel_impl<T, 2>(sat, fvec, direct, relaunch)
+    return nres >= 4 ? persist_kernel_impl<T, 4>(sat, fvec, direct, relaunch)
+         : nres > 0 ? persist_kernel_impl<T, 2>(sat, fvec, direct, relaunch)
                     : persist_kernel_impl<T, 0>(sat, fvec, direct, relaunch);
 }
 

@@ -171,7 +171,7 @@ struct msgw_ctx {
     // persistent RK3 kernel (single rank, coupled)
     int persist = 1;                 // 0 disables (MSGW_PERSIST=0 or after a time-out)
     int service = 1;                 // reducer workgroups beside the workers (MSGW_SERVICE=0: last arriver reduces)
-    int regtiles = 1;                // register-resident tiles in the persistent kernel (MSGW_REGTILES=0 disables)
+    int regtiles = 4;                // most register-resident tiles per workgroup in the persistent kernel (MSGW_REGTILES=0 | 2 | 4)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
     unsigned int *pdone = nullptr;   // PDONE_WORDS: [0] ready, [32..33] done2, [64] final rows, [96] rank rows, [128..] group tickets
     int *pstatus = nullptr;          // raised by a persistent launch whose bounded wait timed out; sticky until the next
@@ -628,6 +628,7 @@ int plan_persist(msgw_ctx *c, int nres, int mode, bool rl, bool multi, PersistPl
     pl = PersistPlan{};
     pl.nres = nres;
     pl.fn = persist_kernel<T>(mode == 1, c->fvec, mode == 2, nres, rl);
+    if (!pl.fn && nres > 2) return MSGW_OK;                    // this variant has no four-tile flavour
     pl.lds = persist_lds_bytes(c);
     if (int rc = ensure_lds(c, pl.fn, pl.lds)) return rc;
     int per_cu = 0;
@@ -648,7 +649,7 @@ int plan_persist(msgw_ctx *c, int nres, int mode, bool rl, bool multi, PersistPl
         split_rays(c, c->n, maxb, &pl.rays_per_block, &pl.tiles_per_block, &blocks);
         // measured with 2 resident tiles: +10 % at 2e6 rays (8 tiles per workgroup), +3 % at 4e6 and 8e6 (16, 32),
         // -10 % at 16e6 (64), where 4 workgroups per CU with all rays streamed are better
-        if (pl.tiles_per_block > 16 * nres) return MSGW_OK;
+        if (pl.tiles_per_block > 32) return MSGW_OK;
     } else if (blocks + PERSIST_GROUPS + 2 > slots) {
         // tall columns: the LDS footprint leaves fewer than the default 4 workgroups per CU
         const long long maxb = slots - (PERSIST_GROUPS + 2);
@@ -687,7 +688,9 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     bool want = c->persist && can_fuse && (!multi || c->xch_ok);
     PersistPlan pl;
     bool fits = false;
-    if (want && c->regtiles)                                   // first choice: register-resident tiles
+    if (want && c->regtiles > 2)                               // first choice: four register-resident tiles,
+        if (int rc = plan_persist<T>(c, 4, mode, rl, multi, pl, &fits)) return rc;
+    if (want && c->regtiles && !fits)                          // then two,
         if (int rc = plan_persist<T>(c, 2, mode, rl, multi, pl, &fits)) return rc;
     if (want && !fits)
         if (int rc = plan_persist<T>(c, 0, mode, rl, multi, pl, &fits)) return rc;
@@ -1174,7 +1177,7 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     c->cnt.elem_bytes = (int32_t)c->esz;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
-    if (const char *e = std::getenv("MSGW_REGTILES")) c->regtiles = std::atoi(e) ? 1 : 0;
+    if (const char *e = std::getenv("MSGW_REGTILES")) c->regtiles = std::atoi(e) >= 4 ? 4 : (std::atoi(e) ? 2 : 0);
     *out = c;
     return MSGW_OK;
 }

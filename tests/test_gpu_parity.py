@@ -324,7 +324,7 @@ def _tall_case(ngrid, n, seed=77):
     return s, st
 
 
-@pytest.mark.parametrize("ngrid,env,persist", [(301, {}, True), (301, {"MSGW_REGTILES": "0"}, True),
+@pytest.mark.parametrize("ngrid,env,persist", [(301, {}, True), (301, {"MSGW_REGTILES": "0"}, True), (301, {"MSGW_REGTILES": "2"}, True),
                                                (301, {"MSGW_PERSIST": "0"}, False), (131, {}, True),
                                                (600, {}, True), (600, {"MSGW_SERVICE": "0"}, True)])
 def test_tall_column_path_vs_c_oracle(monkeypatch, ngrid, env, persist):
@@ -433,6 +433,31 @@ def test_persistent_kernel_equals_per_stage_kernels(monkeypatch):
     check_state(outs["1"], outs["0"], 1e-11, 1e-11, "persist-vs-per-stage")
     want = COracle(s).step(60.0, 43, st)
     check_state(outs["1"], want, 1e-9, 1e-9, "persist-vs-oracle")
+
+
+@pytest.mark.parametrize("n,flags,fvec", [(1_000_003, 0, False), (123_457, _capi.RELAUNCH, False), (700_001, 0, True),
+                                          (2_100_000, 0, False), (777, 0, False)])
+def test_persistent_flavours_agree(monkeypatch, n, flags, fvec):
+    """Four / two / no register-resident tiles per workgroup (MSGW_REGTILES): the same rays in the same order, only
+    the grouping of the flux sums differs.  The default takes four for float64 without saturation."""
+    s, st = _random_case(n, 52, False, "vector" if fvec else "uniform", True)
+    st[0] = st[0] * 1e-3
+    outs = {}
+    for tiles in ("4", "2", "0"):
+        monkeypatch.setenv("MSGW_REGTILES", tiles)
+        p = make_prop(s, st)
+        p.step(60.0, 2, flags)
+        p.step(60.0, 9, flags)
+        outs[tiles] = gpu_state(p, st)
+        c = p.counters()
+        assert c["persist_steps"] == 9
+        want_tiles = int(tiles) if n < 8_000_000 else 0
+        assert c["persist_resident_tiles"] == want_tiles, (tiles, c["persist_resident_tiles"])
+        p.close()
+    check_state(outs["4"], outs["2"], 1e-11, 1e-11, "4 vs 2 resident tiles")
+    check_state(outs["4"], outs["0"], 1e-11, 1e-11, "4 resident tiles vs streamed")
+    if not flags:
+        check_state(outs["4"], COracle(s).step(60.0, 11, st), 1e-10, 1e-10, "4 resident tiles vs oracle")
 
 
 @pytest.mark.parametrize("ngrid", [5, 6, 9])

@@ -33,7 +33,7 @@ def run(budget=120.0, seed=1, max_exp=6.4, verbose=True):
             s, st = _random_case(n, int(rng.integers(1 << 30)), sat, vec, bool(rng.random() < 0.7))
             st[0] = st[0] * 1e-3
             res = {}
-            mode = dict(MSGW_REGTILES=str(int(rng.random() < 0.6)), MSGW_SERVICE=str(int(rng.random() < 0.7)))
+            mode = dict(MSGW_REGTILES=str(int(rng.choice([0, 2, 4, 4]))), MSGW_SERVICE=str(int(rng.random() < 0.7)))
             exchange = rng.random() < 0.25                     # the multi-rank path with a 1-rank communicator
             for persist in ("1", "0"):
                 os.environ["MSGW_PERSIST"] = persist
