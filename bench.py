@@ -345,9 +345,14 @@ def main():
                         "traffic": traffic, "traffic_source": traffic_note,
                         "hbm_counter_gbs": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9,
                         "hbm_counter_frac": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "limiter": ("FP64 VALU + dependent latency (PMC: VALU ~57 % busy at 2 waves per SIMD); measured HBM "
-                                    "traffic is about half the algorithmic bytes" if W["dtype"] == "f64" and wl == "config3"
-                                    else None),
+                        "limiter": {"config3": "dependent FP64 latency chains at 2 wavefronts per SIMD (PMC: VALU 56 % busy, waves "
+                                               "waiting half of their cycles); the persistent kernel keeps the evolving ray state "
+                                               "in registers, so the measured HBM traffic is well below the algorithmic bytes",
+                                    "config5": "latency at 2 wavefronts per SIMD (PMC: VALU 41 % busy) plus LDS atomics of "
+                                               "wavefronts whose rays span many levels (dispersed packet)",
+                                    "config2": "1e5 rays are 196 workgroups on 256 CUs: one wavefront per SIMD, latency of the "
+                                               "sqrt / division chains (PMC: VALU 41 % busy); the state never leaves the registers"
+                                    }.get(wl) if persist_steps else None,
                         "kernel_ms_avg": kern_ms,
                         "algorithmic_bytes_per_launch": per_launch_bytes,
                         "events": "HIP events around every launch, " +

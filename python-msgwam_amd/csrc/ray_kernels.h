@@ -629,6 +629,13 @@ __device__ __forceinline__ void load_tile(TileRegs<T> &t, const StageArgsT<T> a,
     if (CGMEM) loadv(a.r.cg(), t.off, t.cg);
 }
 
+// Streamed tiles of the resident-tile flavours carry cg_rr of their state through memory instead of re-evaluating it
+// (16 B per ray-stage for a sqrt and three divisions).  With four resident tiles a workgroup only has streamed
+// tiles beyond 1e6 rays per GPU, where the kernel runs at the HBM ceiling: there the bytes are the dearer side.
+#ifndef CGMEM_MAX_NRES
+#define CGMEM_MAX_NRES 2
+#endif
+
 // LDS views shared by the stage kernels
 template <typename T>
 struct StageLds {
@@ -703,7 +710,7 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
     (void)s_rho2; (void)ng;
     // with resident tiles the kernel is FP64-VALU bound, not HBM bound: streamed tiles then carry cg_rr of
     // their state through memory (8 B store + 8 B load per ray-stage) instead of re-evaluating it
-    constexpr bool CGMEM = NRES > 0 && LAG && DEPOSIT && !SAT && !DIRECT;
+    constexpr bool CGMEM = NRES > 0 && NRES <= CGMEM_MAX_NRES && LAG && DEPOSIT && !SAT && !DIRECT;
     DepWindow acc;                                           // the wave's level sums of this pass
     acc.clear();
     // resident tiles first: they are the workgroup's first NRES tiles, so the deposit order is ray order
