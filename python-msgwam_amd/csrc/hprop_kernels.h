@@ -18,8 +18,11 @@ struct HpropArgs {
     double rad_earth, two_rot, df2c;               // RAD_EARTH, 2*ROT_EARTH, 8*ROT_EARTH**2 (:489)
 };
 
+#ifndef HPROP_WG_PER_CU
+#define HPROP_WG_PER_CU 3
+#endif
 template <int STAGE, bool SAT>
-__global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
+__global__ void __launch_bounds__(BLOCK, HPROP_WG_PER_CU) k_ray_stage_hprop(const HpropArgs h)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const StageArgs a = h.s;
@@ -67,13 +70,11 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
         loadv(a.r.drr(), i0, drr); loadv(h.kk, i0, kk); loadv(h.ll, i0, ll); loadv(a.r.mm(), i0, mm);
         loadv(a.r.vol(), i0, vol);
         if (SAT) loadv(a.r.pvf(), i0, pvf);
-        if (STAGE == 1 || STAGE == 2) {
-            loadv(h.q_lam, i0, qla); loadv(h.q_phi, i0, qph); loadv(a.r.q_rr(), i0, qr); loadv(h.q_kk, i0, qk);
-            loadv(h.q_ll, i0, ql); loadv(a.r.q_mm(), i0, qm);
-            if (SAT) loadv(a.r.q_dens(), i0, qd);
-        }
+        // (the RK registers are loaded AFTER the physics: 28 VGPRs less at its peak, which is what keeps three
+        // workgroups per CU -- 168 VGPRs -- free of heavy spills; the kernel is latency-bound)
         double lo[2], up[2], pay[2][2];
         double n_dens[2], n_lam[2], n_phi[2], n_rr[2], n_kk[2], n_ll[2], n_mm[2];
+        double tend[7][2];
         int nlo[2], nup[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -121,19 +122,29 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_hprop(const HpropArgs h)
             deposit_indices<2>(lo[r], up[r], valid[r], a.dzs, a.inv_dzs, a.mk_ok, nc - 2, nlo[r], nup[r]);
             pay[0][r] = cgr * kk[r] * dens[r];                                      // :148-149
             pay[1][r] = cgr * ll[r] * dens[r];
+            tend[0][r] = st_dens; tend[1][r] = st_lam; tend[2][r] = st_phi; tend[3][r] = st_rr;
+            tend[4][r] = st_kk; tend[5][r] = st_ll; tend[6][r] = st_mm;
+        }
+        asm volatile("" ::: "memory");                         // keep the loads below from being hoisted over the physics
+        if (STAGE == 1 || STAGE == 2) {
+            loadv(h.q_lam, i0, qla); loadv(h.q_phi, i0, qph); loadv(a.r.q_rr(), i0, qr); loadv(h.q_kk, i0, qk);
+            loadv(h.q_ll, i0, ql); loadv(a.r.q_mm(), i0, qm);
+            if (SAT) loadv(a.r.q_dens(), i0, qd);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
             if (STAGE == 3) {
-                n_dens[r] = st_dens; n_lam[r] = st_lam; n_phi[r] = st_phi; n_rr[r] = st_rr;
-                n_kk[r] = st_kk; n_ll[r] = st_ll; n_mm[r] = st_mm;
+                n_dens[r] = tend[0][r]; n_lam[r] = tend[1][r]; n_phi[r] = tend[2][r]; n_rr[r] = tend[3][r];
+                n_kk[r] = tend[4][r]; n_ll[r] = tend[5][r]; n_mm[r] = tend[6][r];
             } else {
-                const double st[7] = {st_dens, st_lam, st_phi, st_rr, st_kk, st_ll, st_mm};
                 const double y[7] = {dens[r], lam[r], phi[r], rr[r], kk[r], ll[r], mm[r]};
                 double q[7] = {qd[r], qla[r], qph[r], qr[r], qk[r], ql[r], qm[r]};
                 double yn[7];
 #pragma unroll
                 for (int v = 0; v < 7; ++v) {                                       // :693-698
-                    if (STAGE == 0) { q[v] = a.dt * st[v]; yn[v] = y[v] + div_const(q[v], 3.0, third_rn<double>(), 1); }
-                    else if (STAGE == 1) { q[v] = a.dt * st[v] - RK_A1 * q[v]; yn[v] = y[v] + RK_B1 * q[v]; }
-                    else { q[v] = a.dt * st[v] - RK_A2 * q[v]; yn[v] = y[v] + RK_B2 * q[v]; }
+                    if (STAGE == 0) { q[v] = a.dt * tend[v][r]; yn[v] = y[v] + div_const(q[v], 3.0, third_rn<double>(), 1); }
+                    else if (STAGE == 1) { q[v] = a.dt * tend[v][r] - RK_A1 * q[v]; yn[v] = y[v] + RK_B1 * q[v]; }
+                    else { q[v] = a.dt * tend[v][r] - RK_A2 * q[v]; yn[v] = y[v] + RK_B2 * q[v]; }
                 }
                 n_dens[r] = SAT ? yn[0] : dens[r];
                 n_lam[r] = yn[1]; n_phi[r] = yn[2]; n_rr[r] = yn[3]; n_kk[r] = yn[4]; n_ll[r] = yn[5]; n_mm[r] = yn[6];
