@@ -18,8 +18,9 @@ struct HpropArgs {
     double rad_earth, two_rot, df2c;               // RAD_EARTH, 2*ROT_EARTH, 8*ROT_EARTH**2 (:489)
 };
 
+// (three workgroups per CU -- 168 VGPRs, 20-38 of them spilled in stages 1, 2 -- measured slower: 173.7 vs 161.5 us per step)
 #ifndef HPROP_WG_PER_CU
-#define HPROP_WG_PER_CU 3
+#define HPROP_WG_PER_CU 2
 #endif
 template <int STAGE, bool SAT>
 __global__ void __launch_bounds__(BLOCK, HPROP_WG_PER_CU) k_ray_stage_hprop(const HpropArgs h)
@@ -70,8 +71,7 @@ __global__ void __launch_bounds__(BLOCK, HPROP_WG_PER_CU) k_ray_stage_hprop(cons
         loadv(a.r.drr(), i0, drr); loadv(h.kk, i0, kk); loadv(h.ll, i0, ll); loadv(a.r.mm(), i0, mm);
         loadv(a.r.vol(), i0, vol);
         if (SAT) loadv(a.r.pvf(), i0, pvf);
-        // (the RK registers are loaded AFTER the physics: 28 VGPRs less at its peak, which is what keeps three
-        // workgroups per CU -- 168 VGPRs -- free of heavy spills; the kernel is latency-bound)
+        // (the RK registers are loaded after the physics; the kernel is latency-bound)
         double lo[2], up[2], pay[2][2];
         double n_dens[2], n_lam[2], n_phi[2], n_rr[2], n_kk[2], n_ll[2], n_mm[2];
         double tend[7][2];
