@@ -16,6 +16,7 @@ struct HpropArgs {
     double *q_lam, *q_phi, *q_kk, *q_ll;           // their low-storage RK registers (STAGE 3: the tendencies)
     const double *uu, *vv;                         // the column on grids, for uu_ray / vv_ray (:357-358)
     double rad_earth, two_rot, df2c;               // RAD_EARTH, 2*ROT_EARTH, 8*ROT_EARTH**2 (:489)
+    int group_reduce;                              // 1: in-kernel reduction of the flux rows (flush_rows_group)
 };
 
 // (three workgroups per CU -- 168 VGPRs, 20-38 of them spilled in stages 1, 2 -- measured slower: 173.7 vs 161.5 us per step)
@@ -171,7 +172,10 @@ __global__ void __launch_bounds__(BLOCK, HPROP_WG_PER_CU) k_ray_stage_hprop(cons
                            ncp, lane, wmin, wmax, acc);
     }
     flush_window(acc, s_rows + wave * 2 * ncp, ncp, lane);
-    flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
+    // the workgroups' rows are reduced inside the launch (ticketed, fixed order: the per-stage kernel's protocol) to the
+    // one row the column kernel reads -- or, for the single-RHS probe, left as sparse rows for k_flux_reduce1
+    if (STAGE != 3 && h.group_reduce) flush_rows_group<2, double>(s_rows, ncp, s_rng, lds, tid, a);
+    else flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
 }
 
 }   // namespace msgw

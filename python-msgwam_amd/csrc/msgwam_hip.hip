@@ -917,14 +917,29 @@ int launch_hprop_stage(msgw_ctx *c, int stage, const HpropArgs &h)
     return launch_struct(c, hprop_kernel(stage, c->sat_online != 0), c->blocks, BLOCK, hprop_lds_bytes(c), h);
 }
 
+// The stage kernels of the HPROP / N(z) chains reduce their flux rows inside the launch (flush_rows_group: one row in
+// c->flux) when a thread of the last reducer can own a column entry; the column kernel then only updates.
+bool chain_group_reduce(const msgw_ctx *c)
+{
+    static const bool off = [] { const char *e = std::getenv("MSGW_CHAIN_GROUPRED"); return e && std::atoi(e) == 0; }();
+    return !off && 2 * (c->ng - 2) <= BLOCK;
+}
+int column_from_row(msgw_ctx *c, int stage, const ColArgs &a)
+{
+    if (c->nranks > 1 || (c->force_coll && c->comm))
+        if (int rc = allreduce_flux(c)) return rc;
+    return launch_column(c, stage, COL_UPDATE, a);
+}
+
 int enqueue_steps_hprop(msgw_ctx *c, double dt, unsigned flags, int count)
 {
-    const HpropArgs h = make_hprop_args(c, dt, flags);
+    HpropArgs h = make_hprop_args(c, dt, flags);
+    h.group_reduce = chain_group_reduce(c) ? 1 : 0;
     const ColArgs ca = make_col_args(c, dt, flags);
     for (int step = 0; step < count; ++step)
         for (int s = 0; s < 3; ++s) {
             if (int rc = launch_hprop_stage(c, s, h)) return rc;
-            if (int rc = column_stage(c, s, ca)) return rc;
+            if (int rc = h.group_reduce ? column_from_row(c, s, ca) : column_stage(c, s, ca)) return rc;
         }
     return MSGW_OK;
 }
@@ -946,12 +961,13 @@ int launch_nz_stage(msgw_ctx *c, int stage, const NzArgs &h)
 
 int enqueue_steps_nz(msgw_ctx *c, double dt, unsigned flags, int count)
 {
-    const NzArgs h = make_nz_args(c, dt, flags);
+    NzArgs h = make_nz_args(c, dt, flags);
+    h.group_reduce = chain_group_reduce(c) ? 1 : 0;
     const ColArgs ca = make_col_args(c, dt, flags);
     for (int step = 0; step < count; ++step)
         for (int s = 0; s < 3; ++s) {
             if (int rc = launch_nz_stage(c, s, h)) return rc;
-            if (int rc = column_stage(c, s, ca)) return rc;
+            if (int rc = h.group_reduce ? column_from_row(c, s, ca) : column_stage(c, s, ca)) return rc;
         }
     return MSGW_OK;
 }

@@ -17,6 +17,7 @@ struct NzArgs {
     double *q_drr, *q_dmm;                         // their low-storage RK registers (STAGE 3: the tendencies)
     const double *dkdl, *area;                     // dkk*dll and rr_mm_area per ray (:594, :599, :137)
     const double *bvf;                             // [ng-1] N on grids
+    int group_reduce;                              // 1: in-kernel reduction of the flux rows (flush_rows_group)
 };
 
 template <int STAGE, bool SAT>
@@ -159,7 +160,10 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_nz(const NzArgs h)
                                    ncp, lane, wmin, wmax, acc);
     }
     flush_window(acc, s_rows + wave * 2 * ncp, ncp, lane);
-    flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
+    // the workgroups' rows are reduced inside the launch (ticketed, fixed order: the per-stage kernel's protocol) to the
+    // one row the column kernel reads -- or, for the single-RHS probe, left as sparse rows for k_flux_reduce1
+    if (STAGE != 3 && h.group_reduce) flush_rows_group<2, double>(s_rows, ncp, s_rng, lds, tid, a);
+    else flush_rows<2>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
 }
 
 }   // namespace msgw
