@@ -10,14 +10,18 @@ from msgwam_amd import _capi
 from msgwam_amd.spectrum import gaussian_spectrum
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 lprop, grid, grids, uu, vv = bench.column(101)
-sp = gaussian_spectrum(n, grids, lprop.rhobar, alpha=0.01)
-p = _capi.Propagator(101, n)
-p.set_config(0.01, 0.0, 1.0, False)
+# MSGW_TL="f32,sat,rl,alpha=0.5": the config-5 kernel variant instead of the default float64 plain one
+opts = os.environ.get("MSGW_TL", "").split(",")
+alpha = float(([o[6:] for o in opts if o.startswith("alpha=")] or ["0.01"])[0])
+flags = _capi.RELAUNCH if "rl" in opts else 0
+sp = gaussian_spectrum(n, grids, lprop.rhobar, alpha=alpha)
+p = _capi.Propagator(101, n, dtype="f32" if "f32" in opts else "f64")
+p.set_config(0.01, 0.0, 1.0, "sat" in opts)
 p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, uu, vv)
 p.upload_rays(sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], sp["phi"], sp["dkk"], sp["dll"], sp["area"])
 p.set_tuning(int(os.environ.get("MSGW_BLOCKS_PER_CU", 3)), 0)
-p.step(120.0, 20); p.sync(); print("persist_steps", p.counters()["persist_steps"], "blocks", p.counters()["blocks"])
-p.step(120.0, 5); p.sync()
+p.step(120.0, int(os.environ.get("MSGW_TL_PRE", 20)), flags); p.sync(); print("persist_steps", p.counters()["persist_steps"], "blocks", p.counters()["blocks"])
+p.step(120.0, 5, flags); p.sync()
 nb = p.counters()["blocks"]; NP = 16
 buf = np.zeros((nb, NP, 4), dtype=np.uint64)
 rc = p.lib.msgw_debug_stamps(p.ctx, buf.ctypes.data_as(C.c_void_p), nb)
