@@ -575,6 +575,31 @@ def _sync_config_only(p):
         _backend.rays = None
 
 
+def _no_rays(dt, var, flags, tendencies):
+    """Zero rays (the reference's numpy code takes empty arrays in its stride: no deposit, the mean flow moves by
+    Coriolis force and pressure gradient alone).  The device library wants at least one ray, so one inert ray
+    (dens = 0) goes through the same kernels; the ray slots come back empty."""
+    _backend.materialize_live()
+    p = _backend.context(len(grid), 1)
+    _sync_config_and_column(p, var[9], var[10], force_uv=True)
+    one = np.ones(1)
+    p.upload_rays(0.0 * one, one, one, 1e-4 * one, 0.0 * one, -1e-3 * one, 1e-4 * one, float(model_config['phi0']) * one,
+                  1e-4 * one, 1e-4 * one, one)
+    if HPROP_GLOBAL:
+        p.upload_hprop(0.0 * one, float(model_config['phi0']) * one)
+    _backend.rays = _backend.col_uv = None                        # nothing of the caller's is resident
+    _backend.gen = {k: v + 1 for k, v in _backend.gen.items()}
+    empty = lambda: np.zeros(0)
+    if tendencies:
+        t = p.rhs(dt, flags)
+        return _pack([empty() for _ in range(9)] + [t['uu'], t['vv']])
+    p.step(dt, 1, flags | _capi.NO_GRAPH)
+    if flags & _capi.FIXED_BACKGROUND:
+        return _pack([var[i] for i in range(11)])
+    uu, vv = p.download_column()
+    return _pack([var[i] for i in range(9)] + [uu, vv])
+
+
 def _prepare(var):
     _check_scope()
     if len(var) != 11:
@@ -626,6 +651,9 @@ def rhs_fixed_background(dt, var_in):
 
 @_guard
 def _rhs(dt, var_in, flags):
+    if len(var_in) == 11 and len(var_in[0]) == 0:
+        _check_scope()
+        return _no_rays(dt, var_in, flags, True)
     p = _prepare(var_in)
     t = p.rhs(dt, flags)
     z = lambda: np.zeros(np.shape(var_in[5]))
@@ -673,6 +701,9 @@ def _as_state(t):
 
 @_guard
 def _rk3_device(dt, var, flags):
+    if len(var) == 11 and len(var[0]) == 0:
+        _check_scope()
+        return _no_rays(dt, var, flags, False)
     p = _prepare(var)
     _backend.protect_live()                                      # unread results of the state that is about to move
     p.step(dt, 1, flags | _capi.NO_GRAPH)

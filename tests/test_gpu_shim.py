@@ -88,6 +88,42 @@ def test_nray_equal_to_levels_works():
     lprop.release_device()
 
 
+def test_zero_rays_move_the_mean_flow_alone():
+    """Empty input: the reference's numpy code runs with zero rays (no deposit; Coriolis force and pressure gradient
+    move the column).  RK3 and rhs_default of the mirror do the same, also as the fixed-background hook."""
+    import msgwam_amd.libprop as lprop
+    from msgwam_amd import driver
+    from oracle import msgwam_oracle as orc
+    grid, grids, uu, vv = driver.configure(ngrid=101)
+    lprop.model_config['phi0'] = 0.4
+    vv = 0.3 * uu[::-1].copy()
+    lprop.set_pressure_gradient(uu, 0 * vv)                     # vv is out of balance: it must move
+    e = np.zeros(0)
+    lprop.set_statics(dkk=e, dll=e, rr_mm_area=e)
+    s = orc.Setup(grid, phi0=0.4, dkk=e, dll=e, rr_mm_area=e)
+    s.set_pressure_gradient(uu, 0 * vv)
+    st = _obj([e] * 9 + [uu, vv])
+    want = st
+    got = st
+    for _ in range(3):
+        want = orc.rk3(s, 120.0, want)
+        got = lprop.RK3(120.0, got)
+    assert got.shape == (11,) and all(np.shape(got[i]) == (0,) for i in range(9))
+    for i in (9, 10):
+        assert np.max(np.abs(np.asarray(got[i]) - want[i])) <= 1e-13 * np.max(np.abs(want[9]))
+    assert np.max(np.abs(np.asarray(got[10]) - vv)) > 1e-6
+    t = lprop.rhs_default(120.0, st)
+    tw = orc.rhs(s, 120.0, st)
+    for i in (9, 10):
+        assert np.max(np.abs(t[i] - tw[i])) <= 1e-13 * np.max(np.abs(tw[9]))
+    lprop.set_model_setup(rhs=lprop.rhs_fixed_background)
+    frozen = lprop.RK3(120.0, st)
+    assert np.array_equal(np.asarray(frozen[9]), uu) and np.array_equal(np.asarray(frozen[10]), vv)
+    lprop.set_model_setup(rhs=lprop.rhs_default)
+    lprop.model_config['phi0'] = 0.0
+    lprop.release_device()
+
+
 def test_scope_errors_are_loud():
     import msgwam_amd.libprop as lprop
     d = load("g3_rk3_coupled_driver")
