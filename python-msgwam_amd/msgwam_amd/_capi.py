@@ -232,6 +232,9 @@ class Propagator:
         a = [_c(np.broadcast_to(x, (n,))) for x in (dens, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, fray)]
         G = _c(G)
         out = np.empty(self._proj_shape(var, len(G)))
+        if n == 0:                                               # nothing to project (the library wants n >= 1)
+            out[...] = 0.0
+            return out
         self._chk(self.lib.msgw_project_arrays(self.ctx, n, int(var), float(bvf), *[_p(x) for x in a],
                                                _p(G), len(G), _p(out)), "msgw_project_arrays")
         return out
@@ -242,6 +245,8 @@ class Propagator:
         a = [_c(np.broadcast_to(x, (n,))) for x in (dens, rr_center, rr_center_st, drr, drr_st, kk, ll,
                                                     mm_center, mm_center_st, dkk, dll, rr_mm_area)]
         out = np.empty(n)
+        if n == 0:
+            return out
         self._chk(self.lib.msgw_saturation(self.ctx, n, float(dt), int(bool(direct)), *[_p(x) for x in a],
                                            _p(out)), "msgw_saturation")
         return out

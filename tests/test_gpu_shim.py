@@ -116,6 +116,11 @@ def test_zero_rays_move_the_mean_flow_alone():
     tw = orc.rhs(s, 120.0, st)
     for i in (9, 10):
         assert np.max(np.abs(t[i] - tw[i])) <= 1e-13 * np.max(np.abs(tw[9]))
+    for var in (0, 1, 2, 3, 4):                                 # the other two hot-path entry points, empty as well
+        proj = lprop.wave_projection(e, e, e, e, e, e, e, e, e, e, e, e, grids, var=var)
+        nG = len(grids)
+        assert proj.shape == {0: (2, nG - 1), 1: (nG - 1,), 2: (nG - 1,), 3: (nG,), 4: (2, nG)}[var] and not proj.any()
+    assert lprop.saturation(120.0, e, e, e, e, e, e, e, e, e, direct=True).shape == (0,)
     lprop.set_model_setup(rhs=lprop.rhs_fixed_background)
     frozen = lprop.RK3(120.0, st)
     assert np.array_equal(np.asarray(frozen[9]), uu) and np.array_equal(np.asarray(frozen[10]), vv)
