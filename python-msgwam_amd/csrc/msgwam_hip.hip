@@ -119,7 +119,7 @@ struct msgw_ctx {
     // rays: float64 (default) or float32 (MSGW_DTYPE_F32) SoA arrays
     int f32 = 0;
     size_t esz = sizeof(double);     // bytes per element of the ray arrays
-    int tile = Real<double>::TILE;   // rays per workgroup iteration (16 B per lane per array)
+    int tile = Real<double>::TILE;   // rays per workgroup iteration (2 rays per lane)
     std::vector<void *> ray_bufs;    // further per-ray allocations (the HPROP arrays)
     char *slab = nullptr;            // ONE allocation for the A_COUNT per-ray arrays, array k at slab + k * pitch
     size_t pitch = 0;                // bytes between two arrays (a multiple of 256)
@@ -285,7 +285,7 @@ int ensure_lds(msgw_ctx *c, const void *kernel, size_t bytes)
 }
 
 // Launch geometry: every workgroup owns `rays_per_block` contiguous rays, a whole number of
-// tiles (512 float64 / 1024 float32 rays), at most ncu*blocks_per_cu workgroups.  Measured and dropped:
+// tiles (512 rays), at most ncu*blocks_per_cu workgroups.  Measured and dropped:
 //  * a finer split of whole tiles that balances the workgroups exactly over the CUs (1009 x 992 rays instead of
 //    977 x 1024 at 1e6 rays): no gain for the per-stage kernels, 4 % slower for the persistent kernel, whose
 //    synchronisation cost grows with the number of workgroups (round 1);

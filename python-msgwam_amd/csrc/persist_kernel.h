@@ -584,7 +584,7 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
 
 // NRES > 0: the first NRES tiles of every ray workgroup are RESIDENT IN REGISTERS for the whole launch
 // (loaded once, written back once): at 2 workgroups per CU a lane has 256 VGPRs, enough for two tiles'
-// state (9 arrays x 16 B per lane each) beside the working set, and the HBM traffic of a pass drops by
+// state (9 arrays x 2 rays per lane each) beside the working set, and the HBM traffic of a pass drops by
 // NRES / tiles_per_block.  Same tile order, same arithmetic: the deposit order is still ray order.
 // RL: the MSGW_RELAUNCH extension (BASELINE config 5) as a compile-time variant, so that the reference-parity
 // kernels carry none of its registers.

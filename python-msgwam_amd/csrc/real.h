@@ -1,8 +1,13 @@
 // Scalar type of the per-ray state: float64 (the reference's, bit-comparable with numpy) or float32
 // (BASELINE config 5: throughput mode, half the bytes per ray).  Everything per ray is templated on
 // `T`; the flux rows, their reduction over workgroups / ranks and the mean-flow column are float64
-// in both modes.  A lane always moves 16 bytes per array access: 2 rays of float64 or
-// 4 rays of float32, so a 256-thread workgroup advances a tile of 512 / 1024 rays.
+// in both modes.  A lane holds 2 rays in both modes (16-B / 8-B accesses per array), so a 256-thread
+// workgroup advances a tile of 512 rays.  (Round 2 first ran float32 with 4 rays per lane -- 16-B accesses, 1024-ray
+// tiles: 1.25e6 rays per GPU are then 2.47 tiles per workgroup, i.e. 407 workgroups of three tiles on 512 slots and
+// wavefronts that span 256 neighbouring rays; with 2 rays per lane the split is 489 x 5 tiles, a wavefront's rays
+// disperse over half as many levels, and FOUR fully resident tiles fit the registers of every float32 variant:
+// config 5 54.7 -> 49.5 us per step.  The price: mostly-streamed runs lose ~6 % to the 8-B accesses, 5e6 rays
+// 2.97 -> 2.78e10 ray-steps/s.  -DMSGW_F32_RPT=4 brings the old layout back.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits>
@@ -22,8 +27,11 @@ template <> struct Real<double> {
     static __device__ __forceinline__ pair_t pair(double x, double y) { return make_double2(x, y); }
     static __device__ __forceinline__ quad_t quad(double x, double y, double z, double w) { return make_double4(x, y, z, w); }
 };
+#ifndef MSGW_F32_RPT
+#define MSGW_F32_RPT 2                            // see the header comment
+#endif
 template <> struct Real<float> {
-    static constexpr int RPT = 4;
+    static constexpr int RPT = MSGW_F32_RPT;
     static constexpr int TILE = BLOCK * RPT;
     typedef float2 pair_t;
     typedef float4 quad_t;
@@ -55,6 +63,15 @@ __device__ __forceinline__ void loadv(const float *p, unsigned int off, float (&
 __device__ __forceinline__ void storev(float *p, unsigned int off, const float (&v)[4])
 {
     *reinterpret_cast<float4 *>(reinterpret_cast<char *>(p) + off) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void loadv(const float *p, unsigned int off, float (&out)[2])
+{
+    const float2 t = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(p) + off);   // 8 B per lane
+    out[0] = t.x; out[1] = t.y;
+}
+__device__ __forceinline__ void storev(float *p, unsigned int off, const float (&v)[2])
+{
+    *reinterpret_cast<float2 *>(reinterpret_cast<char *>(p) + off) = make_float2(v[0], v[1]);
 }
 
 template <typename T> __device__ __forceinline__ T real_inf() { return std::numeric_limits<T>::infinity(); }
