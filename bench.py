@@ -348,8 +348,8 @@ def main():
                         "limiter": {"config3": "dependent FP64 latency chains at 2 wavefronts per SIMD (PMC: VALU 56 % busy, waves "
                                                "waiting half of their cycles); the persistent kernel keeps the evolving ray state "
                                                "in registers, so the measured HBM traffic is well below the algorithmic bytes",
-                                    "config5": "latency at 2 wavefronts per SIMD (PMC: VALU 41 % busy) plus LDS atomics of "
-                                               "wavefronts whose rays span many levels (dispersed packet)",
+                                    "config5": "latency at 2 wavefronts per SIMD (PMC: VALU 48 % busy, waves waiting 57 % of their "
+                                               "cycles); the deposit of a dispersed packet (wavefronts whose rays span many levels)",
                                     "config2": "1e5 rays are 196 workgroups on 256 CUs: one wavefront per SIMD, latency of the "
                                                "sqrt / division chains (PMC: VALU 41 % busy); the state never leaves the registers"
                                     }.get(wl) if persist_steps else None,
