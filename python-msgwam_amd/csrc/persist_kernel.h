@@ -557,7 +557,7 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
     if (q > 0 && tid == 0) seen = __hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // `start` is the first STREAMED ray (the NRES resident tiles before it never leave the registers); a
     // workgroup may have no streamed tile at all (workgroup-uniform test, the arrays are padded by one tile only)
-    constexpr bool CGMEM = NRES > 0 && NRES <= CGMEM_MAX_NRES && !SAT && !DIRECT;   // see process_tiles
+    constexpr bool CGMEM = NRES > 0 && NRES <= CGMEM_MAX_NRES && !SAT;   // see process_tiles
     if (NRES == 0 || start < end) load_tile<T, STAGE, SAT, FVEC, true, DIRECT, CGMEM>(cur, a, start, tid, end);
     if (q > 0) {
         if (!persist_wait_seen(p, q, seen, L.flag, tid, p.ready)) return false;
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
         __syncthreads();
         const StageLds<T> SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
         // (with resident tiles: also leaves cg_rr of the initial state of the streamed tiles in memory)
-        deposit_pass<T, FVEC, (NRES > 0 && NRES <= CGMEM_MAX_NRES && !SAT && !DIRECT)>(a, SL, start, end, tid, wave, lane, start + (long long)NRES * TILE);
+        deposit_pass<T, FVEC, (NRES > 0 && NRES <= CGMEM_MAX_NRES && !SAT)>(a, SL, start, end, tid, wave, lane, start + (long long)NRES * TILE);
         persist_publish(p, L.rows, ncp, L.flag, tid, 0u);
     }
     // resident tiles: everything a stage may read (stage 2 of the DIRECT variant reads the most); lanes

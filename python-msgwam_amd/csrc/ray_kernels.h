@@ -710,7 +710,7 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
     (void)s_rho2; (void)ng;
     // with resident tiles the kernel is FP64-VALU bound, not HBM bound: streamed tiles then carry cg_rr of
     // their state through memory (8 B store + 8 B load per ray-stage) instead of re-evaluating it
-    constexpr bool CGMEM = NRES > 0 && NRES <= CGMEM_MAX_NRES && LAG && DEPOSIT && !SAT && !DIRECT;
+    constexpr bool CGMEM = NRES > 0 && NRES <= CGMEM_MAX_NRES && LAG && DEPOSIT && !SAT;
     DepWindow acc;                                           // the wave's level sums of this pass
     acc.clear();
     // resident tiles first: they are the workgroup's first NRES tiles, so the deposit order is ray order
