@@ -18,11 +18,9 @@ const void *persist_kernel_impl<real_t, MSGW_NRES>(bool sat, bool fvec, bool dir
     return bsel(sat, [&](auto SAT) { return bsel(fvec, [&](auto FVEC) { return bsel(direct, [&](auto DIR) {
         return bsel(relaunch, [&](auto RL) -> const void * {
             if constexpr (decltype(SAT)::value && decltype(DIR)::value) return nullptr;
-            // four resident tiles: every float32 variant (fully resident); float64 only the variants whose resident
-            // state is rr, mm and their RK registers (the saturating ones keep dens, q_dens (rr0, mm0) too and spill
-            // 14-97 VGPRs), see tile_body.inc
-            else if constexpr (MSGW_NRES > 2 && std::is_same<real_t, double>::value &&
-                               (decltype(SAT)::value || decltype(DIR)::value)) return nullptr;
+            // four resident tiles: every float32 variant (fully resident); float64 all but the direct-saturation
+            // variants (whose resident state also holds rr0, mm0: 49-97 spilled VGPRs), see tile_body.inc
+            else if constexpr (MSGW_NRES > 2 && std::is_same<real_t, double>::value && decltype(DIR)::value) return nullptr;
             else return reinterpret_cast<const void *>(
                 &k_rk3_persist<real_t, decltype(SAT)::value, decltype(FVEC)::value, decltype(DIR)::value, MSGW_NRES,
                                decltype(RL)::value>);
