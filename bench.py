@@ -350,8 +350,8 @@ def main():
                                                "in registers, so the measured HBM traffic is well below the algorithmic bytes",
                                     "config5": "latency at 2 wavefronts per SIMD (PMC: VALU 48 % busy, waves waiting 57 % of their "
                                                "cycles); the deposit of a dispersed packet (wavefronts whose rays span many levels)",
-                                    "config2": "1e5 rays are 196 workgroups on 256 CUs: one wavefront per SIMD, latency of the "
-                                               "sqrt / division chains (PMC: VALU 41 % busy); the state never leaves the registers"
+                                    "config2": "1e5 rays are 784 wavefronts for 1024 SIMDs, each issuing its ~200 FP64 instructions "
+                                               "per ray-stage alone (PMC: VALU 41 % busy); the state never leaves the registers"
                                     }.get(wl) if persist_steps else None,
                         "kernel_ms_avg": kern_ms,
                         "algorithmic_bytes_per_launch": per_launch_bytes,
