@@ -5,7 +5,7 @@
 #include "persist_kernel.h"
 
 #if !defined(MSGW_REAL) || !defined(MSGW_NRES)
-#error "compile with -DMSGW_REAL=double|float -DMSGW_NRES=0|2|4"
+#error "compile with -DMSGW_REAL=double|float -DMSGW_NRES=0|2|3|4"
 #endif
 
 namespace msgw {
@@ -20,7 +20,10 @@ const void *persist_kernel_impl<real_t, MSGW_NRES>(bool sat, bool fvec, bool dir
             if constexpr (decltype(SAT)::value && decltype(DIR)::value) return nullptr;
             // four resident tiles: every float32 variant (fully resident); float64 all but the direct-saturation
             // variants (whose resident state also holds rr0, mm0: 49-97 spilled VGPRs), see tile_body.inc
-            else if constexpr (MSGW_NRES > 2 && std::is_same<real_t, double>::value && decltype(DIR)::value) return nullptr;
+            else if constexpr (MSGW_NRES > 3 && std::is_same<real_t, double>::value && decltype(DIR)::value) return nullptr;
+            // three: the float64 direct-saturation variants only (evolving slots incl. rr0, mm0: 32 VGPRs per tile,
+            // 0-6 spilled; 53.0 -> 50.8 us per step at 1e6 rays.  For online saturation three measured like four.)
+            else if constexpr (MSGW_NRES == 3 && !(std::is_same<real_t, double>::value && decltype(DIR)::value)) return nullptr;
             else return reinterpret_cast<const void *>(
                 &k_rk3_persist<real_t, decltype(SAT)::value, decltype(FVEC)::value, decltype(DIR)::value, MSGW_NRES,
                                decltype(RL)::value>);

@@ -45,6 +45,7 @@ template <typename T>
 inline const void *persist_kernel(bool sat, bool fvec, bool direct, int nres, bool relaunch)
 {
     return nres >= 4 ? persist_kernel_impl<T, 4>(sat, fvec, direct, relaunch)
+         : nres == 3 ? persist_kernel_impl<T, 3>(sat, fvec, direct, relaunch)
          : nres > 0 ? persist_kernel_impl<T, 2>(sat, fvec, direct, relaunch)
                     : persist_kernel_impl<T, 0>(sat, fvec, direct, relaunch);
 }

@@ -688,8 +688,10 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     bool want = c->persist && can_fuse && (!multi || c->xch_ok);
     PersistPlan pl;
     bool fits = false;
-    if (want && c->regtiles > 2)                               // first choice: four register-resident tiles,
+    if (want && c->regtiles > 3)                               // first choice: four register-resident tiles,
         if (int rc = plan_persist<T>(c, 4, mode, rl, multi, pl, &fits)) return rc;
+    if (want && c->regtiles > 2 && !fits)                      // three (variants that do not have four),
+        if (int rc = plan_persist<T>(c, 3, mode, rl, multi, pl, &fits)) return rc;
     if (want && c->regtiles && !fits)                          // then two,
         if (int rc = plan_persist<T>(c, 2, mode, rl, multi, pl, &fits)) return rc;
     if (want && !fits)
@@ -1193,7 +1195,7 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     c->cnt.elem_bytes = (int32_t)c->esz;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
-    if (const char *e = std::getenv("MSGW_REGTILES")) c->regtiles = std::atoi(e) >= 4 ? 4 : (std::atoi(e) ? 2 : 0);
+    if (const char *e = std::getenv("MSGW_REGTILES")) c->regtiles = std::atoi(e) >= 4 ? 4 : (std::atoi(e) == 3 ? 3 : (std::atoi(e) ? 2 : 0));
     *out = c;
     return MSGW_OK;
 }

@@ -20,7 +20,7 @@ for dtype in dtypes:
                                   ("relaunch", False, RL, False), ("sat+relaunch", True, RL, False),
                                   ("latitude", False, 0, True), ("sat+latitude", True, 0, True)):
         res = []
-        for env in ({"MSGW_REGTILES": "2"}, {"MSGW_REGTILES": "0"}, {"MSGW_PERSIST": "0"}, {"MSGW_REGTILES": "4"}):
+        for env in ({"MSGW_REGTILES": "2"}, {"MSGW_REGTILES": "0"}, {"MSGW_PERSIST": "0"}, {"MSGW_REGTILES": "4"}, {"MSGW_REGTILES": "3"}):
             for k in ("MSGW_REGTILES", "MSGW_PERSIST"):
                 os.environ.pop(k, None)
             os.environ.update(env)
@@ -35,7 +35,7 @@ for dtype in dtypes:
             c = p.counters()
             res.append((dt / 100 * 1e6, c["persist_steps"], c["persist_resident_tiles"]))
             p.close()
-        print(f"{dtype} {name:14s}: resident {res[0][0]:6.1f} (res {res[0][2]})   streamed {res[1][0]:6.1f}   chain {res[2][0]:6.1f}   four resident {res[3][0]:6.1f} (res {res[3][2]}) us/step", flush=True)
+        print(f"{dtype} {name:14s}: resident {res[0][0]:6.1f} (res {res[0][2]})   streamed {res[1][0]:6.1f}   chain {res[2][0]:6.1f}   four resident {res[3][0]:6.1f} (res {res[3][2]})   three {res[4][0]:6.1f} (res {res[4][2]}) us/step", flush=True)
 if "f64" in dtypes:
     # HPROP_GLOBAL = True: its own per-stage kernel (7 evolving slots per ray)
     for k in ("MSGW_REGTILES", "MSGW_PERSIST"):
