@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="diagnostic: all ranks use GPU 0 (rehearsal of the N>1 path on a 1-GPU box; implies the "
                          "exchange-only communicator because RCCL refuses two ranks on one device; use --backend gloo)")
+    ap.add_argument("--inject-exchange-failure", choices=["device_ipc", "host_shm"], default=None,
+                    help="diagnostic (N>1): the last rank reports a failure of this transport in its first timed region, "
+                         "to exercise the fall-back ladder device_ipc -> host_shm -> rccl")
     ap.add_argument("--kernel-events", choices=["separate", "same", "none"], default="same",
                     help="where the per-launch HIP-event timing of the dominant kernel is taken")
     args = ap.parse_args()
@@ -194,14 +197,25 @@ def main():
     lprop, grid, grids, uu, vv = column(args.ngrid)
     flags = {0: 0, "fixed": _capi.FIXED_BACKGROUND, "relaunch": _capi.RELAUNCH}[W["flags"]]
     same = args.kernel_events == "same"
-    uid = None
     if args.force_collective and world == 1:
         os.environ["MSGW_FORCE_COLLECTIVE"] = "1"
-        uid = _capi.comm_unique_id()
-    if world > 1:
-        box = [_capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+
+    def fresh_uid():
+        """A communicator id of its own for every context that joins one (all ranks call this alike)."""
+        if world > 1:
+            box = [_capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        return _capi.comm_unique_id() if args.force_collective else None
+
+    class ExchangeFailed(RuntimeError):
+        """Some rank's library call failed inside a multi-rank measurement; raised on EVERY rank at the same fence."""
+
+    def all_flag(flag):
+        """max over the ranks of a 0/1 flag (the fence's barrier)"""
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0.5)
 
     def measure(rays, steps, warmup, kernel_events, repeats, pre_steps=0):
         """`repeats` timed regions of `steps` RK3 steps of `rays` rays per rank, state resident."""
@@ -215,35 +229,65 @@ def main():
         p.upload_rays(sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], sp["phi"],
                       sp["dkk"], sp["dll"], sp["area"])
         p.set_tuning(args.blocks_per_cu, args.graph_steps)
+        # Several ranks: a library error on one rank (a time-out in the flux exchange, say) must not leave the others
+        # in a collective.  Library calls are guarded; the error is agreed on at the next fence and raised everywhere.
+        err = [None]
+
+        def safe(fn, *a):
+            if err[0] is None:
+                try:
+                    return fn(*a)
+                except _capi.MsgwError as e:
+                    if dist is None:
+                        raise
+                    err[0] = str(e)
+            return None
+
+        uid = fresh_uid()
         if uid is not None:
-            p.comm_init(uid, rank, world)
+            safe(p.comm_init, uid, rank, world)
+            if dist is not None and all_flag(err[0] is not None):
+                try:
+                    p.close()
+                except Exception:      # noqa: BLE001
+                    pass
+                raise ExchangeFailed(err[0] or "another rank could not set up its communicator")
+        if args.inject_exchange_failure and dist is not None and rank == world - 1 and \
+                _capi.TRANSPORTS.get(p.counters().get("transport", 0)) == args.inject_exchange_failure:
+            injected = f"injected failure of the {args.inject_exchange_failure} transport"   # reported at the next fence
+        else:
+            injected = None
 
         def fence():
-            p.sync()
+            safe(p.sync)
             torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
+            if dist is not None and all_flag(err[0] is not None or injected is not None):
+                try:
+                    p.close()
+                except Exception:      # noqa: BLE001
+                    pass
+                raise ExchangeFailed(err[0] or injected or "another rank reported a failure")
 
         def reset():
             """every repeat times the SAME steps: fresh state, `pre_steps` (late-time measurement only), warm-up"""
-            p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, uu, vv)
-            p.upload_rays(sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], sp["phi"],
-                          sp["dkk"], sp["dll"], sp["area"])
+            safe(p.set_column, grid, grids, lprop.rhobar, lprop.pressure_gradient, uu, vv)
+            safe(p.upload_rays, sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], sp["phi"],
+                 sp["dkk"], sp["dll"], sp["area"])
             done = 0
             while done < pre_steps:                        # late-time measurement: let the packet spread first
                 k = min(200, pre_steps - done)
-                p.step(DT, k, flags)
+                safe(p.step, DT, k, flags)
                 done += k
-            p.step(DT, warmup, flags)
+            safe(p.step, DT, warmup, flags)
 
         walls, kern = [], []
         target_s, r = 0.05, 0
         while True:
             reset()
-            c_prev = p.counters()
             fence()
+            c_prev = p.counters()
             t0 = time.perf_counter()
-            p.step(DT, steps, flags | (_capi.TIME_KERNELS if kernel_events == "same" else 0))
+            safe(p.step, DT, steps, flags | (_capi.TIME_KERNELS if kernel_events == "same" else 0))
             fence()
             wall = time.perf_counter() - t0
             if dist is not None:
@@ -269,8 +313,8 @@ def main():
             if stop or r >= 50:
                 break
         if kernel_events == "separate":                    # HIP events on the library's own stream, second pass
-            p.step(DT, steps, flags | _capi.TIME_KERNELS)
-            p.sync()
+            safe(p.step, DT, steps, flags | _capi.TIME_KERNELS)
+            fence()
             c1 = p.counters()
             nl = c1["ray_kernel_launches"] - c_prev["ray_kernel_launches"]
             kern.append(((c1["ray_kernel_ms_sum"] - c_prev["ray_kernel_ms_sum"]) / max(nl, 1), nl))
@@ -282,7 +326,26 @@ def main():
         return dict(n_total=n_total, n_local=n_local, walls=walls, kern_ms=kern_ms, launches=launches,
                     counters=c1, finite=finite, steps=steps)
 
-    m = measure(rays_per_gpu, args.steps, args.warmup, args.kernel_events, args.repeats)
+    # Several ranks: if the flux exchange fails at run time (it has passed its self-test when the communicator was set
+    # up), every rank learns of it at the same fence and the measurement is repeated one rung down the ladder
+    # device-resident (HIP IPC) -> host shared memory -> RCCL launch chain; the line then says which transport ran.
+    fell_back = []
+    ladder = [None, {"MSGW_XCH_TRANSPORT": "shm"}, {"MSGW_EXCHANGE": "0"}]
+    if os.environ.get("MSGW_EXCHANGE_ONLY"):
+        ladder = ladder[:2]                                    # no RCCL communicator to fall back on
+    m = None
+    for env in ladder:
+        if env:
+            os.environ.update(env)
+        try:
+            m = measure(rays_per_gpu, args.steps, args.warmup, args.kernel_events, args.repeats)
+            break
+        except ExchangeFailed as e:
+            fell_back.append(str(e))
+            if rank == 0:
+                print(f"bench.py: flux exchange failed ({e}); trying the next transport", file=sys.stderr, flush=True)
+    if m is None:
+        raise SystemExit("bench.py: the flux exchange failed on every transport: " + " | ".join(fell_back))
     n_total, n_local, kern_ms, c1, finite = m["n_total"], m["n_local"], m["kern_ms"], m["counters"], m["finite"]
     walls = np.array(m["walls"])
     wall = float(np.median(walls))
@@ -386,6 +449,7 @@ def main():
             "config": {"workload": W["text"],
                        "rays_total": n_total, "rays_per_gpu": rays_per_gpu, "ngrid": args.ngrid,
                        "dt": DT, "parallelism": par, "transport": transport,
+                       **({"transport_fallbacks": fell_back} if fell_back else {}),
                        "graph_steps": c1["graph_steps"], "persist_steps": persist_steps, "blocks": c1["blocks"],
                        "register_resident_tiles_per_workgroup": c1.get("persist_resident_tiles", 0),
                        "timing": "median of `repeats` identical experiments (fresh state, `warmup` steps, then `steps` steps timed)"},

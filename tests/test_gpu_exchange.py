@@ -193,6 +193,34 @@ def test_config4_shard_size_through_the_exchange_vs_c_oracle(monkeypatch, transp
     assert not np.array_equal(got[9], st[9])
 
 
+def _rehearse_bench(extra):
+    import json
+    import socket
+    with socket.socket() as sk:                        # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.join(HERE, "..")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--backend", "gloo", "--share-gpu", "--rays-per-gpu", "60000"] + extra
+    r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out[-3000:]                # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_falls_back_to_the_next_transport_when_the_exchange_fails_at_run_time():
+    """A rank that reports a failure of the device-resident transport inside its first timed region: every rank learns
+    of it at the same fence (nobody is left in a collective), the measurement is repeated through the host
+    shared-memory transport, and the JSON line says so."""
+    d = _rehearse_bench(["--inject-exchange-failure", "device_ipc"])
+    assert d["config"]["transport"] == "host_shm" and d["n_gpus"] == 2 and d["value"] > 0
+    assert len(d["config"]["transport_fallbacks"]) == 1        # (rank 0's view: "another rank reported a failure")
+    assert d["state_finite"] is True and d["roofline"]["kernel"] == "k_rk3_persist"
+
+
 def test_bench_multi_rank_launch_rehearsal(tmp_path):
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per process),
     rehearsed on ONE GPU: --share-gpu puts both ranks on GPU 0 with the exchange-only communicator and
