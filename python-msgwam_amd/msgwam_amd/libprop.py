@@ -263,33 +263,50 @@ class _Snapshot:
 
 
 class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
-    """An evolving slot of the state `RK3` returns (dens, rr, mm, uu, vv; lam, phi, kk, ll with HPROP on).
+    """A slot of the state `RK3` returns.
 
-    It stands for a float64 array that lives in HBM and is copied to the host on first access (indexing, arithmetic,
-    `np.asarray`, assignment into another array ...).  A loop that only feeds the state back into `RK3` never copies
-    anything; a state that is advanced before it was read stays readable (the library keeps a device snapshot of it
-    as long as one of its DeviceArrays is alive).  `lprop.set_lazy_download(False)` makes `RK3` return plain ndarrays.
+    An evolving slot (dens, rr, mm, uu, vv; lam, phi, kk, ll with HPROP on) stands for a float64 array that lives in
+    HBM and is copied to the host on first access (indexing, arithmetic, `np.asarray`, assignment into another array
+    ...); a slot the step did not change holds a private copy of the input.  A loop that only feeds the state back
+    into `RK3` never copies or hashes anything: the object is recognised, and its host copy is READ-ONLY unless it is
+    written through this object (`a[k] = v`, `a += 1`), which marks it for upload.  (`np.asarray(a)` therefore gives a
+    read-only array: copy it to modify it.)  A state that is advanced before it was read stays readable (the library
+    keeps a device snapshot of it as long as one of its DeviceArrays is alive).  `lprop.set_lazy_download(False)`
+    makes `RK3` return plain, writable ndarrays.
     """
     __array_priority__ = 1000
 
-    def __init__(self, backend, name, shape, gen):
+    def __init__(self, backend, name, shape, gen, host=None):
         self._backend, self._name, self._shape, self._gen = backend, name, tuple(shape), gen
         self._kind = "col" if name in ("uu", "vv") else "rays"
-        self._host = None                                   # the materialised ndarray
-        self._mark = None                                   # its digest at download (detects in-place edits)
+        self._host = None                                   # the materialised ndarray (read-only until written through us)
+        self._dirty = False                                 # written through this object: the device no longer matches
         self._snap = None                                   # _Snapshot once the device has moved on
+        if host is not None:                                # a slot the step did not change: a private copy of the input
+            self._host = np.array(host, dtype=np.float64, copy=True)
+            self._host.setflags(write=False)
 
     # -- materialisation -----------------------------------------------------
     def _get(self):
         if self._host is None:
             self._host = self._backend.fetch(self)
-            self._mark = _digest(self._host)
+            self._host.setflags(write=False)                # edits must go through this object (see _writable)
             self._snap = None
         return self._host
 
+    def _writable(self):
+        """The host copy for an in-place edit (`a[k] = v`, `a += 1`): from now on the device no longer matches, and
+        the next hot-path call that gets this object uploads it."""
+        h = self._get()
+        if not self._dirty:
+            h.setflags(write=True)
+            self._dirty = True
+        return h
+
     def _pristine(self):
-        """True when the values on the device are still what this object shows to the caller."""
-        return self._host is None or _digest(self._host) == self._mark
+        """True when the values on the device are still what this object shows to the caller (O(1): the host copy is
+        read-only unless it was written through this object)."""
+        return not self._dirty
 
     # -- ndarray protocol ------------------------------------------------------
     def __array__(self, dtype=None, copy=None):
@@ -300,9 +317,13 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         conv = lambda x: x._get() if isinstance(x, DeviceArray) else x
-        if "out" in kwargs:
-            kwargs["out"] = tuple(conv(x) for x in kwargs["out"])
-        return getattr(ufunc, method)(*[conv(x) for x in inputs], **kwargs)
+        outs = kwargs.get("out")
+        if outs is not None:
+            kwargs["out"] = tuple(x._writable() if isinstance(x, DeviceArray) else x for x in outs)
+        res = getattr(ufunc, method)(*[conv(x) for x in inputs], **kwargs)
+        if outs is not None and any(isinstance(x, DeviceArray) for x in outs):     # `a += 1` must stay this object
+            return outs[0] if len(outs) == 1 else tuple(outs)
+        return res
 
     def __array_function__(self, func, types, args, kwargs):
         if func in (np.shape, np.ndim, np.size) and len(args) == 1 and not kwargs:   # metadata: nothing to copy
@@ -330,7 +351,7 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         return self._get()[k]
 
     def __setitem__(self, k, v):
-        self._get()[k] = v
+        self._writable()[k] = v
 
     def __getattr__(self, name):                            # everything else: the ndarray's own attribute
         if name.startswith("_"):
@@ -341,6 +362,7 @@ class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
         return repr(self._get()) if self._host is not None else f"DeviceArray({self._name}, shape={self._shape}, on device)"
 
 
+_SLOT_NAMES = ("dens", "lam", "phi", "rr", "drr", "kk", "ll", "mm", "dmm", "uu", "vv")
 _EVOLVING = {0: "dens", 3: "rr", 7: "mm", 9: "uu", 10: "vv"}
 _EVOLVING_HPROP = {1: "lam", 2: "phi", 5: "kk", 6: "ll"}
 _EVOLVING_NZ = {4: "drr", 8: "dmm"}                         # with a bvf column (extension)
@@ -460,7 +482,9 @@ def set_lazy_download(on=True):
 def set_residency(mode="safe"):
     """How `RK3` / `rhs_default` decide that a slot the caller passes is already on the device:
       'safe' (default)  the same object as last time AND an unchanged content digest (an in-place edit is seen and
-                        uploaded; costs one pass over the frozen slots per call, ~0.4 ms per 1e6 rays and slot);
+                        uploaded; costs one pass over every writable host array per call, ~0.3 ms per 1e6 rays and
+                        array -- the slots `RK3` returned and read-only arrays (`a.setflags(write=False)`, e.g. the
+                        statics) are recognised by identity alone);
       'fast'            the same object and a strided sample of ~4k values (an edit of a few rays can go unnoticed);
       'off'             nothing is assumed resident: every call uploads every slot (the reference's semantics at
                         the reference's cost model)."""
@@ -493,7 +517,22 @@ def _slot_key(x):
         return ("dev", weakref.ref(x))
     if _residency == "off" or not isinstance(x, np.ndarray):
         return None                                          # lists, scalars ...: converted anew on every call
+    if _frozen(x):
+        return ("host", weakref.ref(x), None)                # cannot be edited in place: the object is its own key
     return ("host", weakref.ref(x), _digest(x) if _residency == "safe" else _sampled(x))
+
+
+def _frozen(x):
+    """An ndarray nobody can write to in place (read-only, and not a view of something writable): recognised by
+    identity alone, in O(1).  `a.setflags(write=False)` on the statics makes the fed-back loop hash nothing."""
+    if x.flags.writeable:
+        return False
+    b = x.base
+    while b is not None:
+        if not isinstance(b, np.ndarray) or b.flags.writeable:
+            return False
+        b = b.base
+    return True
 
 
 def _slot_resident(x, key):
@@ -504,6 +543,8 @@ def _slot_resident(x, key):
         return False
     if key[0] == "dev":
         return x._gen == _backend.gen[x._kind] and x._pristine()
+    if key[2] is None:
+        return _frozen(x)
     return (_digest(x) if _residency == "safe" else _sampled(x)) == key[2]
 
 
@@ -721,18 +762,22 @@ def _rk3_device(dt, var, flags):
     for i in range(11):
         if i in moved:
             out.append(DeviceArray(_backend, moved[i], np.shape(var[i]), _backend.gen["col" if i >= 9 else "rays"]))
-        else:                                                    # unchanged: the caller's own object goes back
+        elif isinstance(var[i], DeviceArray):                    # unchanged, a result of an earlier call: still current
             out.append(var[i])
-            if isinstance(var[i], DeviceArray):                  # (a result of an earlier call: still current)
-                var[i]._gen = _backend.gen[var[i]._kind]
-    if not _lazy:                                                # plain ndarrays, copied now
-        out = [a._get() if isinstance(a, DeviceArray) and i in moved else a for i, a in enumerate(out)]
+            var[i]._gen = _backend.gen[var[i]._kind]
+        elif _lazy and isinstance(var[i], np.ndarray):           # unchanged: a read-only copy that is recognised in O(1)
+            out.append(DeviceArray(_backend, _SLOT_NAMES[i], np.shape(var[i]), _backend.gen["col" if i >= 9 else "rays"],
+                                   host=var[i]))                 # when it comes back (the caller's array would need a digest)
+        else:
+            out.append(var[i])
+    if not _lazy:                                                # plain, writable ndarrays, copied now
+        out = [a._writable() if isinstance(a, DeviceArray) else a for a in out]
     _backend.live = [weakref.ref(a) for a in out if isinstance(a, DeviceArray) and a._host is None]
     # what is on the device now corresponds to `out`
-    for i in moved:
-        if i < 9:
+    for i in range(9):
+        if i in _backend.rays and out[i] is not var[i]:
             _backend.rays[i] = _slot_key(out[i])
-    if 9 in moved:
+    if out[9] is not var[9] or out[10] is not var[10]:
         _backend.col_uv = (_slot_key(out[9]), _slot_key(out[10]))
     return _pack(out)
 

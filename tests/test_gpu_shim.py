@@ -246,7 +246,9 @@ def test_state_fed_back_stays_on_the_device_and_edits_are_seen(monkeypatch):
     try:
         st = _obj(state_from(d, "in"))
         s1 = lprop.RK3(dt, st)
-        assert isinstance(s1[3], lprop.DeviceArray) and s1[5] is st[5]     # evolving: on device; frozen: the caller's
+        assert isinstance(s1[3], lprop.DeviceArray)                        # evolving: on the device
+        assert isinstance(s1[5], lprop.DeviceArray) and np.array_equal(s1[5], st[5])   # unchanged: a read-only copy,
+        assert not np.asarray(s1[5]).flags.writeable and np.asarray(s1[5]) is not st[5]   # recognised in O(1) next time
         state = s1
         for _ in range(9):
             state = lprop.RK3(dt, state)
@@ -258,7 +260,9 @@ def test_state_fed_back_stays_on_the_device_and_edits_are_seen(monkeypatch):
         s = setup_from(d)
         state[0][7] = 0.0                                    # DeviceArray.__setitem__
         kk = state[5]
-        kk[11] *= 1.5                                        # the caller's own ndarray
+        kk[11] *= 1.5                                        # an unchanged slot, through the returned object
+        with pytest.raises(ValueError):
+            np.asarray(state[3])[0] = 1.0                    # the bare host copy is read-only: edits go through the object
         want = orc.rk3(s, dt, [np.asarray(a, dtype=np.float64) for a in state])
         got = lprop.RK3(dt, state)
         for i, k in enumerate(STATE_KEYS):
@@ -268,6 +272,20 @@ def test_state_fed_back_stays_on_the_device_and_edits_are_seen(monkeypatch):
             else:
                 assert relerr(g, want[i]) <= 1e-10, k
         assert got[0][7] == 0.0 and counts["up"] == 2
+        # (3) the caller's ORIGINAL arrays passed again after an in-place edit: seen by the content digest
+        st2 = _obj(state_from(d, "in"))
+        a1 = lprop.RK3(dt, st2)
+        assert counts["up"] == 3
+        st2[5][3] *= 2.0
+        a2 = lprop.RK3(dt, st2)
+        assert counts["up"] == 4 and not np.array_equal(np.asarray(a1[7]), np.asarray(a2[7]))
+        # read-only input arrays are recognised by identity alone
+        for i in range(11):
+            st2[i].setflags(write=False)
+        lprop.rhs_default(dt, st2)                           # (the device has moved on: this uploads st2 again)
+        assert counts["up"] == 5
+        lprop.rhs_default(dt, st2)                           # the same read-only objects: nothing to hash, nothing to upload
+        assert counts["up"] == 5
         # plain ndarrays on request
         lprop.set_lazy_download(False)
         out = lprop.RK3(dt, got)

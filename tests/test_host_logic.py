@@ -1,6 +1,7 @@
 """CPU-only: host-side logic of the product package (no GPU compute): module surface,
 column/initial-condition helpers, spectrum generator and sharding."""
 import numpy as np
+import pytest
 
 from oracle import msgwam_oracle as orc
 from helpers import load
@@ -161,9 +162,22 @@ def test_device_array_is_lazy_and_behaves_like_an_ndarray():
     hist = np.zeros((2, 6))
     hist[1] = a                                              # the driver's `int_rr[nt] = state_out[3]`
     assert np.array_equal(hist[1], np.arange(6)) and b.fetched == 1
-    assert a._pristine()
-    a[3] = -1.0
+    assert a._pristine() and not np.asarray(a).flags.writeable   # the host copy is read-only ...
+    with pytest.raises(ValueError):
+        np.asarray(a)[0] = 5.0
+    a[3] = -1.0                                              # ... until it is written through the object
     assert not a._pristine() and np.asarray(a)[3] == -1.0
+    c = lprop.DeviceArray(b, "kk", (6,), 0, host=np.arange(6.0))   # a slot the step did not change: a private copy
+    assert b.fetched == 1 and c._pristine() and c[2] == 2.0
+    c += 1.0                                                 # in-place arithmetic goes through the object too
+    assert not c._pristine() and c[2] == 3.0
+    ro = np.arange(4.0)
+    assert not lprop._frozen(ro)
+    ro.setflags(write=False)
+    assert lprop._frozen(ro) and not lprop._frozen(np.arange(4.0)[::2]) and lprop._slot_resident(ro, lprop._slot_key(ro))
+    view = np.arange(4.0)[:2]
+    view.setflags(write=False)
+    assert not lprop._frozen(view)                           # a read-only view of a writable array is not trusted
 
 
 def test_residency_fingerprints_see_in_place_edits():
