@@ -19,7 +19,8 @@
  * the reference-parity mode -- or float32 when the context is created with
  * MSGW_DTYPE_F32 (BASELINE config 5: half the bytes per ray, float32 per-ray
  * arithmetic; flux rows, their reduction and the mean-flow column stay float64).
- * Scope: scalar bvf; both HPROP_GLOBAL branches (lib/libprop.py:5).  With
+ * Scope: scalar bvf as in the reference (a bvf COLUMN on grids is an extension, msgw_set_bvf_column, float64
+ * contexts, HPROP off); both HPROP_GLOBAL branches (lib/libprop.py:5).  With
  * HPROP_GLOBAL = False, the driver's configuration (raytracer.py:38), only dens,
  * rr, mm and the uu, vv columns evolve, so only those are copied
  * back; HPROP_GLOBAL = True adds lam, phi, kk, ll (msgw_upload_hprop /
