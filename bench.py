@@ -373,10 +373,13 @@ def main():
             # independent rays: all steps of the call run in ONE launch with rr, mm in registers, so the state
             # touches HBM once per launch; SURVEY 8d counts 48 B per ray-step (state materialised every step),
             # which this kernel does not move -- the HBM roofline does not bound it (FP64 VALU does)
-            per_launch_bytes = bps * n_local
+            per_launch_bytes = bps * persist_steps * n_local
             kernel_name = W["kernel"]
-            fused_note = (f"{persist_steps} steps fused in registers: bytes = one pass over the state per launch; "
-                          "FP64-VALU bound, the HBM fraction is not a quality measure here")
+            fused_note = (f"SURVEY 8d accounting (48 B per ray-step: state materialised once per step) x rays x the "
+                          f"{persist_steps} steps of one launch; the kernel fuses those steps in registers and moves "
+                          "48 B per ray per LAUNCH, so this is an effective rate -- the bound is the FP64 issue rate "
+                          "(PMC: VALU 41 % busy at 1e5 rays, one wavefront per SIMD on 784 of 1024 SIMDs; "
+                          "profiles/r02_config2_summary.md)")
         elif persist_steps:      # one persistent launch covers persist_steps RK3 steps (3 stages each)
             per_launch_bytes = bps * persist_steps * n_local
             kernel_name = "k_rk3_persist"
@@ -453,7 +456,7 @@ def main():
                        "graph_steps": c1["graph_steps"], "persist_steps": persist_steps, "blocks": c1["blocks"],
                        "register_resident_tiles_per_workgroup": c1.get("persist_resident_tiles", 0),
                        "timing": "median of `repeats` identical experiments (fresh state, `warmup` steps, then `steps` steps timed)"},
-            "whole_job_hbm_frac": None if fused_note else value * bps / 1e9 / (HBM_PEAK_GBS * world),
+            "whole_job_hbm_frac": value * bps / 1e9 / (HBM_PEAK_GBS * world),
             "state_finite": finite,
             "roofline": roofline,
         }
