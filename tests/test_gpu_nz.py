@@ -121,6 +121,41 @@ def test_height_dependent_column_at_size_vs_c_oracle():
     p.close()
 
 
+def test_nz_chain_through_the_allreduce_column_path_and_on_a_tall_column(monkeypatch):
+    """Several ranks: the N(z) chain reduces its flux rows inside the stage kernel, all-reduces the row (RCCL) and
+    updates the column; with a 1-rank communicator the all-reduce is the identity, so the results must be BITWISE the
+    plain chain's.  On a column with more than 130 levels the rows are reduced by the separate kernel instead."""
+    s, st = _random_case(20_000, 48, True, "uniform", True)
+    col = _column(s.grids, 4)
+    s.bvf = col
+    p = make_prop_nz(s, st, col)
+    p.step(60.0, 4)
+    want = gpu_state_nz(p, st)
+    p.close()
+    monkeypatch.setenv("MSGW_FORCE_COLLECTIVE", "1")
+    p = make_prop_nz(s, st, col)
+    p.comm_init(_capi.comm_unique_id(), 0, 1)
+    p.step(60.0, 4)
+    got = gpu_state_nz(p, st)
+    p.close()
+    for k, a, b in zip(STATE_KEYS, got, want):
+        assert np.array_equal(a, b, equal_nan=True), k
+    monkeypatch.delenv("MSGW_FORCE_COLLECTIVE")
+    # tall column, against the numpy definition
+    from test_gpu_parity import _tall_case
+    s, st = _tall_case(301, 5_003, seed=8)
+    col = 0.01 * (1 + 0.2 * s.grids / s.grids[-1])
+    s.bvf = col
+    want = st
+    for _ in range(2):
+        want = orc.rk3(s, 60.0, want)
+    p = make_prop_nz(s, st, col)
+    p.step(60.0, 2)
+    got = gpu_state_nz(p, st)
+    p.close()
+    check_state(got, want, 1e-10, 1e-11, "N(z) tall")
+
+
 def test_kat_frequency_conservation_on_the_gpu():
     """The known-answer test of the extension (tests/test_oracle_golden.py) on the GPU: omega is conserved along the
     rays to the time-stepping error while m changes by several per cent."""
