@@ -120,3 +120,21 @@ def test_hprop_through_the_allreduce_column_path(monkeypatch):
     p.close()
     for k, a, b in zip(STATE_KEYS, got, want):
         assert np.array_equal(a, b, equal_nan=True), k
+
+
+def test_hprop_on_a_tall_column():
+    """More than 130 levels: the stage kernel leaves sparse rows and the separate reduce kernel sums them."""
+    from test_gpu_parity import _tall_case
+    rng = np.random.default_rng(3)
+    s, st = _tall_case(301, 6_007, seed=12)
+    st[2] = rng.uniform(-1.0, 1.0, len(st[0]))                 # scattered latitudes
+    s.hprop = True
+    want = st
+    for _ in range(2):
+        want = orc.rk3(s, 60.0, want)
+    p = _prop(s, st)
+    p.step(60.0, 2)
+    got = _state(p, st)
+    p.close()
+    for i, k in enumerate(STATE_KEYS):
+        _close(got[i], want[i], what=("tall", k))
