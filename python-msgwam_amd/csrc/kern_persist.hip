@@ -12,6 +12,23 @@ namespace msgw {
 
 typedef MSGW_REAL real_t;
 
+#ifndef MSGW_LEAN
+#define MSGW_LEAN 0
+#endif
+#if MSGW_LEAN
+// the lean-LDS-layout variants (float64; two or four resident tiles; no direct saturation)
+template <>
+const void *persist_kernel_lean_impl<MSGW_NRES>(bool sat, bool fvec, bool direct, bool relaunch)
+{
+    static_assert(std::is_same<real_t, double>::value && (MSGW_NRES == 2 || MSGW_NRES == 4), "lean: float64, 2 or 4 tiles");
+    if (direct) return nullptr;
+    return bsel(sat, [&](auto SAT) { return bsel(fvec, [&](auto FVEC) {
+        return bsel(relaunch, [&](auto RL) -> const void * {
+            return reinterpret_cast<const void *>(
+                &k_rk3_persist<real_t, decltype(SAT)::value, decltype(FVEC)::value, false, MSGW_NRES, decltype(RL)::value, true>);
+        }); }); });
+}
+#else
 template <>
 const void *persist_kernel_impl<real_t, MSGW_NRES>(bool sat, bool fvec, bool direct, bool relaunch)
 {
@@ -29,5 +46,7 @@ const void *persist_kernel_impl<real_t, MSGW_NRES>(bool sat, bool fvec, bool dir
                                decltype(RL)::value>);
         }); }); }); });
 }
+
+#endif
 
 }   // namespace msgw

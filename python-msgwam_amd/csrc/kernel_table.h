@@ -4,6 +4,7 @@
 // entry point of a variant as an opaque pointer and launches it with hipLaunchKernel /
 // hipExtLaunchKernel.  nullptr = that combination is not built (the host reports MSGW_ERR_UNSUP).
 #pragma once
+#include <type_traits>
 
 namespace msgw {
 
@@ -41,9 +42,17 @@ const void *convert_kernel_f2d();                                               
 // k_rk3_persist<T, ...>; one explicit specialisation per (T, NRES) lives in kern_persist.hip
 template <typename T, int NRES>
 const void *persist_kernel_impl(bool sat, bool fvec, bool direct, bool relaunch);
+// the LEAN LDS layout (persist_kernel.h): float64, two or four resident tiles
+template <int NRES>
+const void *persist_kernel_lean_impl(bool sat, bool fvec, bool direct, bool relaunch);
 template <typename T>
-inline const void *persist_kernel(bool sat, bool fvec, bool direct, int nres, bool relaunch)
+inline const void *persist_kernel(bool sat, bool fvec, bool direct, int nres, bool relaunch, bool lean = false)
 {
+    if (lean) {
+        if (!std::is_same<T, double>::value) return nullptr;
+        return nres >= 4 ? persist_kernel_lean_impl<4>(sat, fvec, direct, relaunch)
+             : nres == 2 ? persist_kernel_lean_impl<2>(sat, fvec, direct, relaunch) : nullptr;
+    }
     return nres >= 4 ? persist_kernel_impl<T, 4>(sat, fvec, direct, relaunch)
          : nres == 3 ? persist_kernel_impl<T, 3>(sat, fvec, direct, relaunch)
          : nres > 0 ? persist_kernel_impl<T, 2>(sat, fvec, direct, relaunch)

@@ -585,8 +585,10 @@ int column_stage(msgw_ctx *c, int stage, const ColArgs &a0)
     return launch_column(c, stage, COL_REDUCE | COL_UPDATE, a);
 }
 
-size_t persist_lds_bytes(const msgw_ctx *c)
+size_t persist_lds_bytes(const msgw_ctx *c, bool lean = false)
 {
+    if (lean) return stage_lds_bytes(c) + 64;                  // the LEAN layout (persist_kernel.h): only the flag words on top
+
     // + column replica (7 x (ng-1) float64) + flags; float32 rays: + the float64 shear table of the column arithmetic
     return stage_lds_bytes(c) + sizeof(double) * (size_t)7 * (c->ng - 1) + 32 +
            (c->f32 ? sizeof(double) * 4 * (size_t)(c->ng - 2) + 32 : 0);
@@ -633,6 +635,18 @@ int plan_persist(msgw_ctx *c, int nres, int mode, bool rl, bool multi, PersistPl
     if (int rc = ensure_lds(c, pl.fn, pl.lds)) return rc;
     int per_cu = 0;
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pl.fn, BLOCK, pl.lds));
+    // tall columns: the lean-LDS variant of the kernel (float64, two or four resident tiles, reducer workgroups on)
+    // when it lets more workgroups share a CU -- never for the default column, whose occupancy the registers decide
+    bool lean = false;
+    if (!c->f32 && c->service && nres > 0) {
+        const void *lf = persist_kernel<T>(mode == 1, c->fvec, mode == 2, nres, rl, true);
+        const size_t ll = persist_lds_bytes(c, true);
+        int per_cu_lean = 0;
+        if (lf && ensure_lds(c, lf, ll) == MSGW_OK &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lean, lf, BLOCK, ll) == hipSuccess && per_cu_lean > per_cu) {
+            lean = true; pl.fn = lf; pl.lds = ll; per_cu = per_cu_lean;
+        }
+    }
     // all workgroups of the grid must be co-resident.  The occupancy query is the device's capacity for THIS
     // process; ranks that share one device (rehearsals on a 1-GPU box) split it evenly (c->tenants, agreed on
     // when the communicator was set up).  A foreign tenant cannot be seen: the bounded waits turn that case
@@ -667,6 +681,7 @@ int plan_persist(msgw_ctx *c, int nres, int mode, bool rl, bool multi, PersistPl
     // + one exchange workgroup
     pl.grid = blocks + pl.nservice + (pl.nservice ? 1 : 0) + ((multi && !pl.nservice) ? 1 : 0);
     *fits = slots >= pl.grid && pl.grid <= 2048;               // every workgroup co-resident
+    if (lean && !pl.nservice) *fits = false;                   // (the lean layout has no room for per-workgroup column replicas)
     return MSGW_OK;
 }
 

@@ -588,7 +588,11 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
 // NRES / tiles_per_block.  Same tile order, same arithmetic: the deposit order is still ray order.
 // RL: the MSGW_RELAUNCH extension (BASELINE config 5) as a compile-time variant, so that the reference-parity
 // kernels carry none of its registers.
-template <typename T, bool SAT, bool FVEC, bool DIRECT, int NRES = 0, bool RL = false>
+// LEAN (float64, tall columns, reducer workgroups on; chosen by the host when it lets more workgroups share a CU): the
+// column workgroup's replica lives in the LDS the ray workgroups use for their wave rows and density table (it needs
+// neither), rhobar and the pressure gradient are read from global memory: 128 instead of 184 B of LDS per level.  A
+// compile-time variant: as a run-time option its pointer selection cost the default column 1.4 % (register allocation).
+template <typename T, bool SAT, bool FVEC, bool DIRECT, int NRES = 0, bool RL = false, bool LEAN = false>
 __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const PersistArgsT<T> p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -599,13 +603,22 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
     const StageCarve<T> C(lds, ng);
     PersistLds<T> L;
     L.sh = C.sh; L.rho2 = C.rho2; L.xg = C.xg; L.gs = C.gs; L.xgd = C.xgd; L.rows = C.rows;
-    double *colrep = L.rows + WAVES * 2 * ncp;
-    L.cu = colrep; L.cv = L.cu + nc; L.cqu = L.cv + nc; L.cqv = L.cqu + nc; L.crho = L.cqv + nc; L.cpg = L.crho + nc;
-    L.flag = reinterpret_cast<int *>(L.cpg + 2 * nc);
+    static_assert(!LEAN || std::is_same<T, double>::value, "the lean LDS layout is float64 only");
+    if constexpr (LEAN) {
+        // wave-row region [8 ncp]: F [2 ng], then cu, cv, cqu, cqv [4 nc]; density-table region [2 nc]: du, dv [2 ni]
+        L.cu = L.rows + 2 * ng; L.cv = L.cu + nc; L.cqu = L.cv + nc; L.cqv = L.cqu + nc;
+        L.crho = const_cast<double *>(a.c.rhobar); L.cpg = const_cast<double *>(a.pg);
+        L.flag = reinterpret_cast<int *>(L.rows + WAVES * 2 * ncp);
+    } else {
+        double *colrep = L.rows + WAVES * 2 * ncp;
+        L.cu = colrep; L.cv = L.cu + nc; L.cqu = L.cv + nc; L.cqv = L.cqu + nc; L.crho = L.cqv + nc; L.cpg = L.crho + nc;
+        L.flag = reinterpret_cast<int *>(L.cpg + 2 * nc);
+    }
     if constexpr (std::is_same<T, double>::value) L.shd = reinterpret_cast<double4 *>(L.sh);
     else                                                       // 32 bytes of flags, then [ni] double4 (32-B aligned)
         L.shd = reinterpret_cast<double4 *>((reinterpret_cast<uintptr_t>(L.flag + 8) + 31) & ~(uintptr_t)31);
     L.F = C.F; L.u = C.u; L.v = C.v; L.du = C.du; L.dv = C.dv;
+    if constexpr (LEAN) { L.du = reinterpret_cast<double *>(C.rho2); L.dv = L.du + ni; }
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #ifdef MSGW_STAMP
@@ -629,10 +642,10 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
     // CU's drain time plus the last workgroup's hand-off is what counts.)
 
     stage_xg(C, a.c, ni, tid);
-    stage_rho(C, a.c, nc, tid, true);
+    if constexpr (!LEAN) stage_rho(C, a.c, nc, tid, true);
     for (int i = tid; i < nc; i += BLOCK) {
         L.cu[i] = p.cin.uu[i]; L.cv[i] = p.cin.vv[i]; L.cqu[i] = 0.0; L.cqv[i] = 0.0;
-        L.crho[i] = a.c.rhobar[i]; L.cpg[i] = a.pg[i]; L.cpg[nc + i] = a.pg[nc + i];
+        if constexpr (!LEAN) { L.crho[i] = a.c.rhobar[i]; L.cpg[i] = a.pg[i]; L.cpg[nc + i] = a.pg[nc + i]; }
     }
     __syncthreads();
     column_shear(tid, BLOCK, ng, a.dzg, L.cu, L.cv, L.du, L.dv);
@@ -643,6 +656,7 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
         persist_column_wg(p, L, tid);
         return;
     }
+    if constexpr (LEAN) stage_rho(C, a.c, nc, tid, true);     // (after the tables: du, dv lived in the density table's LDS)
 
     // deposit-only pre-pass: F_0 = wave_projection(state_0)
     {
