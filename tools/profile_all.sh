@@ -20,7 +20,7 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/bench/r02_bench_config3_drive
 python bench.py --force-collective --no-cpu-baseline --no-size-sweep > gpurun_out/bench/r02_bench_config3_one_rank_exchange.json 2>> gpurun_out/bench/err.log
 MSGW_XCH_TRANSPORT=shm python bench.py --force-collective --no-cpu-baseline --no-size-sweep > gpurun_out/bench/r02_bench_config3_one_rank_exchange_shm.json 2>> gpurun_out/bench/err.log
 MSGW_EXCHANGE=0 python bench.py --force-collective --no-cpu-baseline --no-size-sweep > gpurun_out/bench/r02_bench_config3_one_rank_rccl_chain.json 2>> gpurun_out/bench/err.log
-python tools/tall_probe.py 1000000 201 301 601 > gpurun_out/bench/tall_probe.txt 2>&1
+python tools/tall_probe.py 1000000 201 301 451 601 801 > gpurun_out/bench/tall_probe.txt 2>&1
 python tools/variant_bench.py 1000000 f64 0.01 > gpurun_out/bench/variants_f64.txt 2>&1
 python tools/variant_bench.py 1250000 f32 0.01 > gpurun_out/bench/variants_f32.txt 2>&1
 echo ALLDONE
