@@ -396,7 +396,10 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             try:
                 t = json.load(open(tpath)).get(key)
-                if isinstance(t, dict) and persist_steps:
+                if isinstance(t, dict) and persist_steps and "bytes_per_ray_launch" in t:
+                    traffic = t["bytes_per_ray_launch"] * n_local          # steps fused in registers: once per launch
+                    traffic_note = t.get("source")
+                elif isinstance(t, dict) and persist_steps:
                     traffic = t["bytes_per_ray_step"] * n_local * persist_steps
                     traffic_note = t.get("source")
                 else:
