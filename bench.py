@@ -414,8 +414,10 @@ def main():
                         "traffic": traffic, "traffic_source": traffic_note,
                         "hbm_counter_gbs": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9,
                         "hbm_counter_frac": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "limiter": {"config3": "dependent FP64 latency chains at 2 wavefronts per SIMD (PMC: VALU 56 % busy, waves "
-                                               "waiting half of their cycles); the persistent kernel keeps the evolving ray state "
+                        "limiter": {"config3": "instruction issue of the tile body (about 750 executed instructions per 2-ray lane and RK stage; "
+                                               "PMC: VALU 56 % busy): the time per tile and CU is the same at 8 and at 12 wavefronts per "
+                                               "CU with all state on chip, and serving the static re-reads from a hot 4 KB window gains "
+                                               "3.6 % (DESIGN.md 6); the persistent kernel keeps the evolving ray state "
                                                "in registers, so the measured HBM traffic is well below the algorithmic bytes",
                                     "config5": "latency at 2 wavefronts per SIMD (PMC: VALU 48 % busy, waves waiting 57 % of their "
                                                "cycles); the deposit of a dispersed packet (wavefronts whose rays span many levels)",

@@ -45,6 +45,7 @@
 namespace msgw {
 
 constexpr unsigned int PERSIST_OPT_PRIO = 1u;   // workgroups that trail by a pass run it at raised wave priority
+constexpr unsigned int PERSIST_OPT_PREFETCH = 2u;   // early poll + table prefetch at the pass boundary (persist_publish)
 constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
 constexpr int PD_ROW = 64;               // (unused since the column workgroup does the sum over the ranks itself)
 constexpr int PD_LOCAL = 96;             // ready[PD_LOCAL]: several ranks: fluxes whose rank row is complete
@@ -319,9 +320,19 @@ __device__ __forceinline__ void persist_reduce_final(const PersistArgsT<T> p, un
 // their wait loop -- the reduce chain then reacts only when a reducer happens to be waiting, picks up
 // ~10 us of polling latency and gates everybody (80 -> 88.6 us per step); and phase-staggering the
 // dispatch rounds by up to half a pass at launch (no effect: the offsets relax within a few passes).
+// PREFETCH (register-resident flavours with a column workgroup): the hand-off at a pass boundary used to be three
+// serial L2 round trips and five barriers on the slowest workgroup, the one everybody waits for -- drain the row
+// stores, poll `ready`, load the next pass's shear table.  For exactly that workgroup the table of the NEXT pass has
+// long been published when it gets here (it trails; the lagged deposit gives the reduce chain a whole pass), so lane 0
+// polls `ready` before the workgroup's last resident tile (`polled`, the latency hides behind that tile) and, when the
+// next pass (index f) is already released, the table loads are issued together with the row stores: one round trip,
+// two barriers, and the next pass starts on its tiles at once (returns true: table staged in `sh_dst`, wave rows
+// zeroed).  The control dependency poll -> flag -> barrier -> table loads is kept, and the table slot of pass f is
+// not rewritten before this workgroup has published in pass f (it is rewritten for pass f + 2, which needs that row).
 template <typename T>
-__device__ __forceinline__ void persist_publish(const PersistArgsT<T> p, const double *rows, int ncp, int *s_flag,
-                                                int tid, unsigned int f)
+__device__ __forceinline__ bool persist_publish(const PersistArgsT<T> p, double *rows, int ncp, int *s_flag,
+                                                int tid, unsigned int f, bool try_pre = false, unsigned int polled = 0u,
+                                                T *sh_dst = nullptr)
 {
     const StageArgsT<T> a = p.s;
     const int ncols = 2 * ncp;
@@ -330,19 +341,36 @@ __device__ __forceinline__ void persist_publish(const PersistArgsT<T> p, const d
     const unsigned int par = f & 1u;
     double *part = p.grp_part2 + (size_t)par * nb * a.row_stride;
     unsigned int *ticket = p.grp_cnt2 + ((size_t)par * PERSIST_GROUPS + g) * TICKET_STRIDE;
+    if (try_pre && tid == 0) s_flag[3] = (polled >= f) ? 1 : 0;   // pass f waits for ready >= f (persist_stage)
     __syncthreads();                                          // all waves' rows complete in LDS
+    const bool pre = try_pre && s_flag[3] != 0;               // workgroup-uniform
     double *mine = part + (size_t)b * a.row_stride;
     for (int col = tid; col < ncols; col += BLOCK) {
         double acc = rows[col];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) acc = acc + rows[w * ncols + col];
         st_agent(mine + col, acc);
+        if (pre) {                                            // a thread zeroes exactly the entries it has just read
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) rows[w * ncols + col] = 0.0;
+        }
+    }
+    if (pre) {                                                // table of pass f: slot (f - 1) & 1 (as in persist_stage)
+        const int n4 = 4 * (a.ng - 2);
+        const double *tab = p.shtab + (size_t)((f - 1u) & 1u) * n4;
+        for (int i = tid; i < n4; i += 2 * BLOCK) {           // two loads in flight per trip (one trip up to 130 levels)
+            const int i2 = i + BLOCK;
+            const bool h2 = i2 < n4;
+            const double t0 = ld_agent(tab + i), t1 = ld_agent(tab + (h2 ? i2 : i));
+            sh_dst[i] = (T)t0;
+            if (h2) sh_dst[i2] = (T)t1;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
     __syncthreads();
     if (p.nservice) {                                         // the group's reducer workgroup takes it from here
         if (tid == 0) __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
+        return pre;
     }
     if (tid == 0) {
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -350,7 +378,7 @@ __device__ __forceinline__ void persist_publish(const PersistArgsT<T> p, const d
         s_flag[1] = (t == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;
     }
     __syncthreads();
-    if (!s_flag[1]) return;
+    if (!s_flag[1]) return false;
     persist_reduce_group(p, g, f, ncols, tid);
     if (tid == 0) {
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for flux f+2
@@ -359,8 +387,9 @@ __device__ __forceinline__ void persist_publish(const PersistArgsT<T> p, const d
         s_flag[2] = (t2 == (unsigned int)p.ngroups - 1u) ? 1 : 0;   // last group of this flux?
     }
     __syncthreads();
-    if (!s_flag[2]) return;
+    if (!s_flag[2]) return false;
     persist_reduce_final(p, f, ncols, tid);
+    return false;
 }
 
 // Reducer workgroup of group g (owns no rays; p.nservice of them run beside the workers): for every
@@ -541,7 +570,7 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgsT<T> p, const
 template <typename T, int STAGE, bool SAT, bool FVEC, bool DIRECT, int NRES, bool RL>
 __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const PersistLds<T> L, unsigned int q,
                                               long long start, long long end, int tid, int wave, int lane,
-                                              TileRegs<T> (&res)[NRES > 0 ? NRES : 1])
+                                              TileRegs<T> (&res)[NRES > 0 ? NRES : 1], bool &pre)
 {
     const StageArgsT<T> a = p.s;
     const int ncp = a.ng - 2;
@@ -553,31 +582,42 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
     TileRegs<T> cur;
     // Lane 0's first poll of `ready` is issued before its tile loads: returns are in order, so the
     // poll's result is there after one round trip while the tile's 11 loads are still in flight.
+    // `pre` (workgroup-uniform): the previous pass's publish found this pass released already, staged its table and
+    // zeroed the wave rows (persist_publish, PREFETCH) -- straight to the tiles
     unsigned int seen = 0;
-    if (q > 0 && tid == 0) seen = __hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!pre && q > 0 && tid == 0) seen = __hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // `start` is the first STREAMED ray (the NRES resident tiles before it never leave the registers); a
     // workgroup may have no streamed tile at all (workgroup-uniform test, the arrays are padded by one tile only)
     constexpr bool CGMEM = NRES > 0 && NRES <= CGMEM_MAX_NRES && !SAT;   // see process_tiles
     if (NRES == 0 || start < end) load_tile<T, STAGE, SAT, FVEC, true, DIRECT, CGMEM>(cur, a, start, tid, end);
-    if (q > 0) {
-        if (!persist_wait_seen(p, q, seen, L.flag, tid, p.ready)) return false;
-        if (p.nservice) {                                      // the column workgroup has published this pass's table
-            const double *tab = p.shtab + (size_t)((q - 1u) & 1u) * 4 * (a.ng - 2);
-            T *dst = reinterpret_cast<T *>(L.sh);
-            for (int i = tid; i < 4 * (a.ng - 2); i += BLOCK) dst[i] = (T)ld_agent(tab + i);
-            __syncthreads();
-        } else {
-            persist_column(p, L, q, (STAGE + 2) % 3, tid);
+    if (!pre) {
+        if (q > 0) {
+            if (!persist_wait_seen(p, q, seen, L.flag, tid, p.ready)) return false;
+            if (p.nservice) {                                  // the column workgroup has published this pass's table
+                const double *tab = p.shtab + (size_t)((q - 1u) & 1u) * 4 * (a.ng - 2);
+                T *dst = reinterpret_cast<T *>(L.sh);
+                for (int i = tid; i < 4 * (a.ng - 2); i += BLOCK) dst[i] = (T)ld_agent(tab + i);
+                __syncthreads();
+            } else {
+                persist_column(p, L, q, (STAGE + 2) % 3, tid);
+            }
         }
+        PSTAMP(q, 1);
+        for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
+        __syncthreads();
+    } else {
+        PSTAMP(q, 1);
     }
-    PSTAMP(q, 1);
-    for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
-    __syncthreads();
     int wmin = INT_MAX, wmax = INT_MIN;
     const StageLds<T> SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
-    process_tiles<T, STAGE, SAT, FVEC, true, DIRECT, true, NRES, RL>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax, &res);
+    // PREFETCH (persist_publish): lane 0 polls `ready` before the workgroup's last resident tile
+    const bool try_pre = NRES > 0 && p.nservice != 0 && (p.opts & PERSIST_OPT_PREFETCH) != 0;
+    unsigned int polled = 0u;
+    process_tiles<T, STAGE, SAT, FVEC, true, DIRECT, true, NRES, RL>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax, &res,
+                                                                     try_pre ? p.ready : nullptr, &polled);
     PSTAMP(q, 2);
-    persist_publish(p, L.rows, ncp, L.flag, tid, q + 1u);     // this pass produced state_{q+1}: publish F_{q+1}
+    // this pass produced state_{q+1}: publish F_{q+1}
+    pre = persist_publish(p, L.rows, ncp, L.flag, tid, q + 1u, try_pre, polled, reinterpret_cast<T *>(L.sh));
     PSTAMP(q, 3);
     return true;
 }
@@ -593,7 +633,7 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
 // neither), rhobar and the pressure gradient are read from global memory: 128 instead of 184 B of LDS per level.  A
 // compile-time variant: as a run-time option its pointer selection cost the default column 1.4 % (register allocation).
 template <typename T, bool SAT, bool FVEC, bool DIRECT, int NRES = 0, bool RL = false, bool LEAN = false>
-__global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const PersistArgsT<T> p)
+__global__ void __launch_bounds__(BLOCK, NRES > 0 ? ((MSGW_EXP3 && NRES == 2) ? 3 : 2) : 4) k_rk3_persist(const PersistArgsT<T> p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int TILE = Real<T>::TILE;
@@ -692,12 +732,13 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const P
     }
     const long long sstart = start + (long long)NRES * TILE;    // first streamed ray
     unsigned int q = 0;
+    bool pre = false;
     for (int step = 0; step < p.nsteps; ++step) {
-        if (!persist_stage<T, 0, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res)) return;
+        if (!persist_stage<T, 0, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res, pre)) return;
         ++q;
-        if (!persist_stage<T, 1, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res)) return;
+        if (!persist_stage<T, 1, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res, pre)) return;
         ++q;
-        if (!persist_stage<T, 2, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res)) return;
+        if (!persist_stage<T, 2, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res, pre)) return;
         ++q;
     }
     if constexpr (NRES > 0) {                                  // write the resident tiles back

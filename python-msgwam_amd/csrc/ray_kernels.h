@@ -12,6 +12,10 @@
 #include "column_math.h"
 #include "real.h"
 
+#ifndef MSGW_EXP3
+#define MSGW_EXP3 0     // experiment: two evolving-only resident tiles at THREE workgroups per CU
+#endif
+
 namespace msgw {
 
 constexpr int SPAN_MAX = 8;          // widest per-wave level span on the shuffle path
@@ -696,7 +700,8 @@ template <typename T, int STAGE, bool SAT, bool FVEC, bool DEPOSIT, bool DIRECT,
 __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const StageLds<T> L, TileRegs<T> &cur,
                                               long long start, long long end, int tid, int wave,
                                               int lane, int &wmin, int &wmax,
-                                              TileRegs<T> (*res)[NRES > 0 ? NRES : 1] = nullptr)
+                                              TileRegs<T> (*res)[NRES > 0 ? NRES : 1] = nullptr,
+                                              const unsigned int *poll_ctr = nullptr, unsigned int *polled = nullptr)
 {
     constexpr int RPT = Real<T>::RPT;
     constexpr int TILE = Real<T>::TILE;
@@ -718,6 +723,9 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
         static_assert(NRES == 0 || STAGE != 3, "the single-RHS probe has no resident tiles");
 #pragma unroll
         for (int i = 0; i < NRES; ++i) {
+            // persistent kernel, PREFETCH (persist_kernel.h): lane 0 looks at the release counter one tile before the end
+            if (i == NRES - 1 && poll_ctr && tid == 0)
+                *polled = __hip_atomic_load(poll_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #define TB_T (*res)[i]
 #define TB_RESIDENT true
 #define TB_IDX i
