@@ -5,9 +5,9 @@ import numpy as np
 from msgwam_amd import _capi
 
 
-def make_prop(setup, state, cap=None):
+def make_prop(setup, state, cap=None, dtype="f64"):
     dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = state
-    p = _capi.Propagator(len(setup.grid), cap or len(dens))
+    p = _capi.Propagator(len(setup.grid), cap or len(dens), dtype=dtype)
     p.set_config(setup.bvf, setup.phi0, setup.kappa, setup.saturate_online)
     p.set_column(setup.grid, setup.grids, setup.rhobar, setup.pressure_gradient, uu, vv)
     p.upload_rays(dens, rr, drr, kk, ll, mm, dmm, phi, setup.dkk, setup.dll, setup.rr_mm_area)

@@ -460,6 +460,29 @@ def test_persistent_flavours_agree(monkeypatch, n, flags, fvec):
         check_state(outs["4"], COracle(s).step(60.0, 11, st), 1e-10, 1e-10, "4 resident tiles vs oracle")
 
 
+@pytest.mark.parametrize("n,flags,regtiles,dtype", [(1_000_003, 0, "4", "f64"), (300_001, _capi.RELAUNCH, "2", "f64"),
+                                                     (1_250_000, 0, "4", "f32"), (4_100_000, 0, "4", "f64")])
+def test_table_prefetch_is_bitwise_neutral(monkeypatch, n, flags, regtiles, dtype):
+    """The early poll + shear-table prefetch at the pass boundary of the resident-tile flavours (persist_publish,
+    MSGW_PREFETCH=0 | 1, on by default) changes WHEN a workgroup stages the next pass's table and zeroes its wave rows,
+    never a value or a summation order: the states with and without it are bit for bit the same (resident tiles only,
+    resident + streamed tiles, relaunch variant, float32 rays)."""
+    s, st = _random_case(n, 77, False, "uniform", True)
+    st[0] = st[0] * 1e-3
+    monkeypatch.setenv("MSGW_REGTILES", regtiles)
+    outs = {}
+    for pre in ("1", "0"):
+        monkeypatch.setenv("MSGW_PREFETCH", pre)
+        p = make_prop(s, st, dtype=dtype)
+        p.step(60.0, 1, flags)
+        p.step(60.0, 7, flags)
+        outs[pre] = gpu_state(p, st)
+        assert p.counters()["persist_steps"] == 7
+        p.close()
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 @pytest.mark.parametrize("ngrid", [5, 6, 9])
 def test_smallest_columns_vs_c_oracle(ngrid):
     """ngrid = 5 is the smallest column the library accepts (the scratch of the fused mean-flow update, 6*ngrid - 6
