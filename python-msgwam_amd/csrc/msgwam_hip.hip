@@ -632,6 +632,8 @@ int plan_persist(msgw_ctx *c, int nres, int mode, bool rl, bool multi, PersistPl
     pl.nres = nres;
     pl.fn = persist_kernel<T>(mode == 1, c->fvec, mode == 2, nres, rl);
     if (!pl.fn && nres > 2) return MSGW_OK;                    // this variant has no four-tile flavour
+    // the resident-tile flavours assume the exact constant division by the grid spacing (process_tiles: mk_ok)
+    if (nres > 0 && !markstein_ok((T)c->dzs)) return MSGW_OK;
     pl.lds = persist_lds_bytes(c);
     if (int rc = ensure_lds(c, pl.fn, pl.lds)) return rc;
     int per_cu = 0;

@@ -275,12 +275,18 @@ __device__ __forceinline__ Bracket<T> interp_locate(T x, const T *xp, int n, T x
     int j = (int)((x - x0) * inv_dx);
     j = min(max(j, 0), n - 2);
     T xj = xp[j], xj1 = xp[j + 1];
-    while (x < xj && j > 0) { --j; xj1 = xj; xj = xp[j]; }
-    while (x >= xj1 && j < n - 2) { ++j; xj = xj1; xj1 = xp[j + 1]; }
+    // On a uniform grid the guess is the bracket except within a rounding error of a grid point, so the fix-up loops
+    // sit behind ONE test that practically no lane passes (as plain loops their first trips -- an LDS read, a wait
+    // and exec-mask bookkeeping each -- ran for every ray: ~30 instructions per ray and RK stage).
+    const bool low = (x < xj) & (j > 0), high = (x >= xj1) & (j < n - 2);
+    if (__builtin_expect(low | high, 0)) {
+        while (x < xj && j > 0) { --j; xj1 = xj; xj = xp[j]; }
+        while (x >= xj1 && j < n - 2) { ++j; xj = xj1; xj1 = xp[j + 1]; }
+    }
     const bool top = x >= x_last;                   // beyond or on the last point -> fp[n-1]
     b.j = top ? n - 1 : j;
     b.xj = xj;
-    b.flat = (top || x < x_first || x == xj) ? 1 : 0;
+    b.flat = (int)(top | (x < x_first) | (x == xj));   // (bitwise: no short-circuit branches)
     return b;
 }
 template <typename T>
@@ -303,14 +309,18 @@ __device__ __forceinline__ T np_trunc_index(T t)
 // significand is all ones (the host clears `ok` then).  3 VALU ops instead of the ~14 of an
 // IEEE fp64 division; bit-identical to numpy's `x / d` (checked on 2.4e8 samples on the CPU and
 // by the bit-exact parity tests).  Non-finite x goes through the plain product (inf stays inf).
-template <typename T>
+// ANYNAN = true: the caller treats a NaN result like an infinite one (np_trunc_index maps both to INT64_MIN) or only
+// uses the result for finite x (the overlap of a contributing ray volume), so the final finite-x select is dropped
+// (a class compare, its hazard slot and two v_cndmask per call; twice per ray and once per ray and level).
+template <bool ANYNAN = false, typename T>
 __device__ __forceinline__ T div_const(T x, T d, T c, int ok)
 {
     if constexpr (std::is_same<T, float>::value) return x * c;   // float32: no bit-level pin (see real.h)
-    if (!ok) return x / d;
+    if (__builtin_expect(!ok, 0)) return x / d;
     const T q = x * c;
     const T r = fma(-d, q, x);
     const T q2 = fma(r, c, q);
+    if constexpr (ANYNAN) return q2;
     return (fabs(x) < real_inf<T>()) ? q2 : q;
 }
 template <typename T> __device__ __forceinline__ T third_rn() { return T(1) / T(3); }
@@ -325,8 +335,8 @@ template <typename T> __device__ __forceinline__ T third_rn() { return T(1) / T(
 template <int NP, typename T>
 __device__ __forceinline__ void deposit_indices(T lo, T up, bool valid, T dz, T cdz, int ok, int nzmax, int &nlo, int &nup)
 {
-    const T nl = np_trunc_index(div_const(lo, dz, cdz, ok));               // :124
-    const T nu = np_trunc_index(div_const(up, dz, cdz, ok) + T(1));        // :125
+    const T nl = np_trunc_index(div_const<true>(lo, dz, cdz, ok));         // :124 (inf / NaN -> INT64_MIN either way)
+    const T nu = np_trunc_index(div_const<true>(up, dz, cdz, ok) + T(1));  // :125
     const T nz = (T)nzmax;                                   // :127
     const bool ood = ((nl >= nz) && (nu >= nz)) || ((nl <= T(0)) && (nu <= T(0)));   // :129-130
     nlo = (int)fmin(fmax(nl, T(0)), nz);                     // :133-134
@@ -401,15 +411,16 @@ __device__ __forceinline__ void deposit_tile(const T (&lo)[Real<T>::RPT], const 
             const T g0 = sG[c], g1 = sG[c + 1];              // LDS broadcast reads
             T s[NP];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) s[p] = T(0);
-#pragma unroll
             for (int r = 0; r < RPT; ++r) {
-                const bool in = (c >= nlo[r]) && (c < nup[r]);
-                const T zmin = (g0 > lo[r]) ? g0 : lo[r];               // :157
-                const T zmax = (g1 < up[r]) ? g1 : up[r];               // :158
-                const T wv = div_const(fabs(zmax - zmin), dz, cdz, ok) * vol[r];   // :160, :162
+                const bool in = (c >= nlo[r]) & (c < nup[r]);
+                const T zmin = max1(g0, lo[r]);                         // :157 (one instruction, see real.h)
+                const T zmax = min1(g1, up[r]);                         // :158
+                const T wv = div_const<true>(fabs(zmax - zmin), dz, cdz, ok) * vol[r];   // :160, :162
 #pragma unroll
-                for (int p = 0; p < NP; ++p) s[p] = s[p] + (in ? wv * pay[p][r] : T(0));
+                for (int p = 0; p < NP; ++p) {
+                    const T term = in ? wv * pay[p][r] : T(0);
+                    s[p] = (r == 0) ? term : s[p] + term;               // (no 0 + x: the compiler may not fold it)
+                }
             }
             if (NP == 2) {
                 const double t = (double)wave_sum2_halves(s[0], s[NP - 1]);
@@ -424,9 +435,9 @@ __device__ __forceinline__ void deposit_tile(const T (&lo)[Real<T>::RPT], const 
         for (int r = 0; r < RPT; ++r) {
             for (int c = nlo[r]; c < nup[r]; ++c) {
                 const T g0 = sG[c], g1 = sG[c + 1];
-                const T zmin = (g0 > lo[r]) ? g0 : lo[r];
-                const T zmax = (g1 < up[r]) ? g1 : up[r];
-                const T wv = div_const(fabs(zmax - zmin), dz, cdz, ok) * vol[r];
+                const T zmin = max1(g0, lo[r]);
+                const T zmax = min1(g1, up[r]);
+                const T wv = div_const<true>(fabs(zmax - zmin), dz, cdz, ok) * vol[r];
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
                     __hip_atomic_fetch_add(&row[p * ncp + c], (double)(wv * pay[p][r]), __ATOMIC_RELAXED,
@@ -718,6 +729,10 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
     constexpr bool CGMEM = NRES > 0 && NRES <= CGMEM_MAX_NRES && LAG && DEPOSIT && !SAT;
     DepWindow acc;                                           // the wave's level sums of this pass
     acc.clear();
+    // The exact constant division (div_const) has a run-time fall-back for grid spacings whose significand is all ones;
+    // the resident-tile flavours of the persistent kernel are only launched when it is not needed (plan_persist), so
+    // that the test and its branches leave their level loop (twice per ray, once per ray and level).
+    const int mk_ok = NRES > 0 ? 1 : a.mk_ok;
     // resident tiles first: they are the workgroup's first NRES tiles, so the deposit order is ray order
     if constexpr (NRES > 0) {
         static_assert(NRES == 0 || STAGE != 3, "the single-RHS probe has no resident tiles");

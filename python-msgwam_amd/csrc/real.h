@@ -74,6 +74,15 @@ __device__ __forceinline__ void storev(float *p, unsigned int off, const float (
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(p) + off) = make_float2(v[0], v[1]);
 }
 
+// max / min of two values in ONE instruction (v_max / v_min; a `(a > b) ? a : b` costs a compare, its hazard slot and two
+// v_cndmask per float64).  Used where the operands cannot be NaN (the overlap of a contributing ray volume with a grid
+// cell, lib/libprop.py:157-158: rays with a NaN bound are out of domain and never reach the level loop); for such
+// operands it equals the select form up to the sign of a zero, which the caller's |zmax - zmin| removes.
+__device__ __forceinline__ double max1(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double min1(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max1(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float min1(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 template <typename T> __device__ __forceinline__ T real_inf() { return std::numeric_limits<T>::infinity(); }
 
 // Division and square root of the per-ray arithmetic.  float64: IEEE (correctly rounded, bit-comparable with numpy).
