@@ -289,6 +289,36 @@ __device__ __forceinline__ Bracket<T> interp_locate(T x, const T *xp, int n, T x
     b.flat = (int)(top | (x < x_first) | (x == xj));   // (bitwise: no short-circuit branches)
     return b;
 }
+// The same look-up in two steps, so that a caller can issue the LDS reads of ALL its rays before waiting for any of
+// them: `interp_guess_fetch` (no branch) reads the guessed bracket's abscissae and, speculatively, the table entry it
+// points to; `interp_settle` makes the bracket exact (the rare fix-up re-reads the entry).  Same result as
+// interp_locate followed by tab[b.j]; one LDS round trip per tile instead of two dependent ones per ray.
+template <typename T, typename Q>
+__device__ __forceinline__ void interp_guess_fetch(T x, const T *xp, const Q *tab, int n, T x_last, T x0, T inv_dx,
+                                                   int &j, T &xj, T &xj1, Q &q)
+{
+    j = (int)((x - x0) * inv_dx);
+    j = min(max(j, 0), n - 2);
+    xj = xp[j]; xj1 = xp[j + 1];
+    q = tab[(x >= x_last) ? n - 1 : j];
+}
+template <typename T, typename Q>
+__device__ __forceinline__ Bracket<T> interp_settle(T x, const T *xp, const Q *tab, int n, T x_first, T x_last,
+                                                    int j, T xj, T xj1, Q &q)
+{
+    Bracket<T> b;
+    const bool top = x >= x_last;                   // beyond or on the last point -> fp[n-1]
+    const bool low = (x < xj) & (j > 0), high = (x >= xj1) & (j < n - 2);
+    if (__builtin_expect(low | high, 0)) {
+        while (x < xj && j > 0) { --j; xj1 = xj; xj = xp[j]; }
+        while (x >= xj1 && j < n - 2) { ++j; xj = xj1; xj1 = xp[j + 1]; }
+        q = tab[top ? n - 1 : j];
+    }
+    b.j = top ? n - 1 : j;
+    b.xj = xj;
+    b.flat = (int)(top | (x < x_first) | (x == xj));
+    return b;
+}
 template <typename T>
 __device__ __forceinline__ T interp_eval(T x, const Bracket<T> &b, T fpj, T slj)
 {
