@@ -12,6 +12,9 @@
 #include "column_math.h"
 #include "real.h"
 
+#ifndef MSGW_PREFKL
+#define MSGW_PREFKL 1       // resident tiles read kk, ll one tile ahead (tile_body.inc)
+#endif
 #ifndef MSGW_EXP3
 #define MSGW_EXP3 0     // experiment: two evolving-only resident tiles at THREE workgroups per CU
 #endif
@@ -772,10 +775,12 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
             if (i == NRES - 1 && poll_ctr && tid == 0)
                 *polled = __hip_atomic_load(poll_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #define TB_T (*res)[i]
+#define TB_NEXT (*res)[(i + 1) % NRES]
 #define TB_RESIDENT true
 #define TB_IDX i
 #include "tile_body.inc"
 #undef TB_T
+#undef TB_NEXT
 #undef TB_RESIDENT
 #undef TB_IDX
         }
@@ -786,10 +791,12 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
         if (base >= end) break;                              // workgroup-uniform
         const bool more = (t + 1 < a.tiles_per_block - NRES) && (base + TILE < end);
 #define TB_T cur
+#define TB_NEXT cur
 #define TB_RESIDENT false
 #define TB_IDX t
 #include "tile_body.inc"
 #undef TB_T
+#undef TB_NEXT
 #undef TB_RESIDENT
 #undef TB_IDX
         MSGW_STAMP_AT(3 + 2 * (t & 1));
