@@ -171,6 +171,7 @@ struct msgw_ctx {
     // persistent RK3 kernel (single rank, coupled)
     int persist = 1;                 // 0 disables (MSGW_PERSIST=0 or after a time-out)
     int service = 1;                 // reducer workgroups beside the workers (MSGW_SERVICE=0: last arriver reduces)
+    int balance = 1;                 // laggard workgroups of a CU raise their wave priority (MSGW_BALANCE=0 | 1)
     int prefetch = 1;                // early poll + table prefetch at the pass boundary of the resident-tile flavours (MSGW_PREFETCH=0 | 1)
     int regtiles = 4;                // most register-resident tiles per workgroup in the persistent kernel (MSGW_REGTILES=0 | 2 | 4)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
@@ -738,6 +739,7 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.opts = pl.nservice ? 0u : PERSIST_OPT_PRIO;
     if (const char *e = std::getenv("MSGW_PRIO")) pa.opts = std::atoi(e) ? PERSIST_OPT_PRIO : 0u;
     if (c->prefetch) pa.opts |= PERSIST_OPT_PREFETCH;
+    if (c->balance && pl.nres > 0 && pl.nservice) pa.opts |= PERSIST_OPT_BALANCE;
     pa.grp_rows2 = c->grp_rows2;
     pa.grp_part2 = c->grp_part2;
     pa.flux2 = c->flux2;
@@ -1214,6 +1216,7 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     c->cnt.elem_bytes = (int32_t)c->esz;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
+    if (const char *e = std::getenv("MSGW_BALANCE")) c->balance = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_PREFETCH")) c->prefetch = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_REGTILES")) c->regtiles = std::atoi(e) >= 4 ? 4 : (std::atoi(e) == 3 ? 3 : (std::atoi(e) ? 2 : 0));
     *out = c;

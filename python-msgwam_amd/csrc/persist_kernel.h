@@ -45,6 +45,7 @@
 namespace msgw {
 
 constexpr unsigned int PERSIST_OPT_PRIO = 1u;   // workgroups that trail by a pass run it at raised wave priority
+constexpr unsigned int PERSIST_OPT_BALANCE = 4u;    // a workgroup that finds its pass released on arrival raises its wave priority (persist_stage)
 constexpr unsigned int PERSIST_OPT_PREFETCH = 2u;   // early poll + table prefetch at the pass boundary (persist_publish)
 constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
 constexpr int PD_ROW = 64;               // (unused since the column workgroup does the sum over the ranks itself)
@@ -211,6 +212,7 @@ __device__ __forceinline__ bool persist_wait_seen(const PersistArgsT<T> p, unsig
         int ok = 1;
         if (seen > target) ok = 3;                             // bit 1: the next flux is final too, i.e. this workgroup trails
         if (seen < target) {
+            ok |= 4;                                           // bit 2: this workgroup had to wait for the release
             const unsigned long long t0 = wall_clock64();
             while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(8);
@@ -237,7 +239,14 @@ __device__ __forceinline__ bool persist_wait_seen(const PersistArgsT<T> p, unsig
         if (r & 2) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(0);
     }
-    return r != 0;
+    // BALANCE: of the two workgroups of a CU the older one wins the issue arbitration, finishes its tiles first and then
+    // idles until the younger one -- whose loop is the period -- has caught up (tools/persist_timeline.py: tiles 6.6 vs
+    // 8.5 us).  A workgroup that did not have to wait is the laggard of its CU and runs the pass at raised priority.
+    if ((p.opts & PERSIST_OPT_BALANCE) && (int)blockIdx.x < p.nworkers) {   // (ray workgroups only)
+        if (r & 4) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(2);
+    }
+    return (r & 3) != 0;
 }
 
 template <typename T>
@@ -606,6 +615,7 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
         for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
         __syncthreads();
     } else {
+        if (p.opts & PERSIST_OPT_BALANCE) __builtin_amdgcn_s_setprio(2);
         PSTAMP(q, 1);
     }
     int wmin = INT_MAX, wmax = INT_MIN;
