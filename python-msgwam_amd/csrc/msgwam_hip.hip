@@ -739,7 +739,12 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.opts = pl.nservice ? 0u : PERSIST_OPT_PRIO;
     if (const char *e = std::getenv("MSGW_PRIO")) pa.opts = std::atoi(e) ? PERSIST_OPT_PRIO : 0u;
     if (c->prefetch) pa.opts |= PERSIST_OPT_PREFETCH;
-    if (c->balance && pl.nres > 0 && pl.nservice) pa.opts |= PERSIST_OPT_BALANCE;
+    if (c->balance && pl.nres > 0 && pl.nservice) {
+        // MSGW_BALANCE=<abc> (diagnostic): priorities of a workgroup released on arrival / that had to wait / prefetched
+        const int b = c->balance == 1 ? 202 : c->balance;
+        pa.opts |= PERSIST_OPT_BALANCE | ((unsigned)((b / 100) % 10 & 3) << 4) | ((unsigned)((b / 10) % 10 & 3) << 6) |
+                   ((unsigned)(b % 10 & 3) << 8);
+    }
     pa.grp_rows2 = c->grp_rows2;
     pa.grp_part2 = c->grp_part2;
     pa.flux2 = c->flux2;
@@ -1216,7 +1221,7 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     c->cnt.elem_bytes = (int32_t)c->esz;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
-    if (const char *e = std::getenv("MSGW_BALANCE")) c->balance = std::atoi(e) ? 1 : 0;
+    if (const char *e = std::getenv("MSGW_BALANCE")) c->balance = std::atoi(e);
     if (const char *e = std::getenv("MSGW_PREFETCH")) c->prefetch = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_REGTILES")) c->regtiles = std::atoi(e) >= 4 ? 4 : (std::atoi(e) == 3 ? 3 : (std::atoi(e) ? 2 : 0));
     *out = c;

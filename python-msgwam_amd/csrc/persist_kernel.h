@@ -45,6 +45,14 @@
 namespace msgw {
 
 constexpr unsigned int PERSIST_OPT_PRIO = 1u;   // workgroups that trail by a pass run it at raised wave priority
+__device__ __forceinline__ void setprio_rt(unsigned int v)    // s_setprio takes an immediate
+{
+    if (v == 0u) __builtin_amdgcn_s_setprio(0);
+    else if (v == 1u) __builtin_amdgcn_s_setprio(1);
+    else if (v == 2u) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+// BALANCE priorities in opts: bits 4-5 released on arrival, 6-7 had to wait, 8-9 prefetched (persist_publish)
 constexpr unsigned int PERSIST_OPT_BALANCE = 4u;    // a workgroup that finds its pass released on arrival raises its wave priority (persist_stage)
 constexpr unsigned int PERSIST_OPT_PREFETCH = 2u;   // early poll + table prefetch at the pass boundary (persist_publish)
 constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
@@ -243,8 +251,8 @@ __device__ __forceinline__ bool persist_wait_seen(const PersistArgsT<T> p, unsig
     // idles until the younger one -- whose loop is the period -- has caught up (tools/persist_timeline.py: tiles 6.6 vs
     // 8.5 us).  A workgroup that did not have to wait is the laggard of its CU and runs the pass at raised priority.
     if ((p.opts & PERSIST_OPT_BALANCE) && (int)blockIdx.x < p.nworkers) {   // (ray workgroups only)
-        if (r & 4) __builtin_amdgcn_s_setprio(0);
-        else __builtin_amdgcn_s_setprio(2);
+        if (r & 4) setprio_rt((p.opts >> 6) & 3u);
+        else setprio_rt((p.opts >> 4) & 3u);
     }
     return (r & 3) != 0;
 }
@@ -615,7 +623,7 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
         for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
         __syncthreads();
     } else {
-        if (p.opts & PERSIST_OPT_BALANCE) __builtin_amdgcn_s_setprio(2);
+        if (p.opts & PERSIST_OPT_BALANCE) setprio_rt((p.opts >> 8) & 3u);
         PSTAMP(q, 1);
     }
     int wmin = INT_MAX, wmax = INT_MIN;
