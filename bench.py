@@ -414,11 +414,11 @@ def main():
                         "traffic": traffic, "traffic_source": traffic_note,
                         "hbm_counter_gbs": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9,
                         "hbm_counter_frac": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "limiter": {"config3": "instruction issue of the tile body (about 750 executed instructions per 2-ray lane and RK stage; "
-                                               "PMC: VALU 56 % busy): the time per tile and CU is the same at 8 and at 12 wavefronts per "
-                                               "CU with all state on chip, and serving the static re-reads from a hot 4 KB window gains "
-                                               "3.6 % (DESIGN.md 6); the persistent kernel keeps the evolving ray state "
-                                               "in registers, so the measured HBM traffic is well below the algorithmic bytes",
+                        "limiter": {"config3": "dependent LDS / memory round trips inside the tile body at 2 wavefronts per SIMD, and the younger of a "
+                                               "CU's two workgroups (its loop -- table 1.3 + tiles 8.2 + publish 1.3 us -- is the pass period; the "
+                                               "reduce chain, 9.2 us from the last row to the release, is close behind); the persistent kernel "
+                                               "keeps the evolving ray state in registers, so the measured HBM traffic is well below the "
+                                               "algorithmic bytes (DESIGN.md 6)",
                                     "config5": "latency at 2 wavefronts per SIMD (PMC: VALU 48 % busy, waves waiting 57 % of their "
                                                "cycles); the deposit of a dispersed packet (wavefronts whose rays span many levels)",
                                     "config2": "1e5 rays are 784 wavefronts for 1024 SIMDs, each issuing its ~200 FP64 instructions "

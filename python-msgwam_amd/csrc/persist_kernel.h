@@ -347,9 +347,9 @@ __device__ __forceinline__ void persist_reduce_final(const PersistArgsT<T> p, un
 // zeroed).  The control dependency poll -> flag -> barrier -> table loads is kept, and the table slot of pass f is
 // not rewritten before this workgroup has published in pass f (it is rewritten for pass f + 2, which needs that row).
 template <typename T>
-__device__ __forceinline__ bool persist_publish(const PersistArgsT<T> p, double *rows, int ncp, int *s_flag,
-                                                int tid, unsigned int f, bool try_pre = false, unsigned int polled = 0u,
-                                                T *sh_dst = nullptr)
+__device__ __forceinline__ int persist_publish(const PersistArgsT<T> p, double *rows, int ncp, int *s_flag,
+                                               int tid, unsigned int f, bool try_pre = false, unsigned int polled = 0u,
+                                               T *sh_dst = nullptr)
 {
     const StageArgsT<T> a = p.s;
     const int ncols = 2 * ncp;
@@ -367,11 +367,15 @@ __device__ __forceinline__ bool persist_publish(const PersistArgsT<T> p, double 
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) acc = acc + rows[w * ncols + col];
         st_agent(mine + col, acc);
-        if (pre) {                                            // a thread zeroes exactly the entries it has just read
+        if (try_pre) {                                        // a thread zeroes exactly the entries it has just read
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) rows[w * ncols + col] = 0.0;
         }
     }
+    // second chance (the early poll came too soon): lane 0 looks again, the answer arrives behind the row stores at no
+    // cost; a released pass then starts with its table load instead of a poll round trip (return value 2)
+    unsigned int polled2 = 0u;
+    if (try_pre && !pre && tid == 0) polled2 = __hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (pre) {                                                // table of pass f: slot (f - 1) & 1 (as in persist_stage)
         const int n4 = 4 * (a.ng - 2);
         const double *tab = p.shtab + (size_t)((f - 1u) & 1u) * n4;
@@ -384,10 +388,14 @@ __device__ __forceinline__ bool persist_publish(const PersistArgsT<T> p, double 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
+    if (try_pre && !pre && tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only (the table is read with sc1 loads)
+        s_flag[6] = (polled2 >= f) ? 1 : 0;                    // (its own word: s_flag[3] may still be being read)
+    }
     __syncthreads();
     if (p.nservice) {                                         // the group's reducer workgroup takes it from here
         if (tid == 0) __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return pre;
+        return pre ? 1 : ((try_pre && s_flag[6] != 0) ? 2 : 0);
     }
     if (tid == 0) {
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -395,7 +403,7 @@ __device__ __forceinline__ bool persist_publish(const PersistArgsT<T> p, double 
         s_flag[1] = (t == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;
     }
     __syncthreads();
-    if (!s_flag[1]) return false;
+    if (!s_flag[1]) return 0;
     persist_reduce_group(p, g, f, ncols, tid);
     if (tid == 0) {
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for flux f+2
@@ -404,9 +412,9 @@ __device__ __forceinline__ bool persist_publish(const PersistArgsT<T> p, double 
         s_flag[2] = (t2 == (unsigned int)p.ngroups - 1u) ? 1 : 0;   // last group of this flux?
     }
     __syncthreads();
-    if (!s_flag[2]) return false;
+    if (!s_flag[2]) return 0;
     persist_reduce_final(p, f, ncols, tid);
-    return false;
+    return 0;
 }
 
 // Reducer workgroup of group g (owns no rays; p.nservice of them run beside the workers): for every
@@ -587,7 +595,7 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgsT<T> p, const
 template <typename T, int STAGE, bool SAT, bool FVEC, bool DIRECT, int NRES, bool RL>
 __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const PersistLds<T> L, unsigned int q,
                                               long long start, long long end, int tid, int wave, int lane,
-                                              TileRegs<T> (&res)[NRES > 0 ? NRES : 1], bool &pre)
+                                              TileRegs<T> (&res)[NRES > 0 ? NRES : 1], int &pre)
 {
     const StageArgsT<T> a = p.s;
     const int ncp = a.ng - 2;
@@ -602,14 +610,18 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
     // `pre` (workgroup-uniform): the previous pass's publish found this pass released already, staged its table and
     // zeroed the wave rows (persist_publish, PREFETCH) -- straight to the tiles
     unsigned int seen = 0;
-    if (!pre && q > 0 && tid == 0) seen = __hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // pre == 2: the publish already saw this pass released (no poll), rows zeroed; pre == 0 with try_pre: rows zeroed too
+    const bool try_pre = NRES > 0 && p.nservice != 0 && (p.opts & PERSIST_OPT_PREFETCH) != 0;
+    if (pre == 0 && q > 0 && tid == 0) seen = __hip_atomic_load(p.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // `start` is the first STREAMED ray (the NRES resident tiles before it never leave the registers); a
     // workgroup may have no streamed tile at all (workgroup-uniform test, the arrays are padded by one tile only)
     constexpr bool CGMEM = NRES > 0 && NRES <= CGMEM_MAX_NRES && !SAT;   // see process_tiles
     if (NRES == 0 || start < end) load_tile<T, STAGE, SAT, FVEC, true, DIRECT, CGMEM>(cur, a, start, tid, end);
-    if (!pre) {
+    if (pre != 1) {
         if (q > 0) {
-            if (!persist_wait_seen(p, q, seen, L.flag, tid, p.ready)) return false;
+            if (pre == 0) {
+                if (!persist_wait_seen(p, q, seen, L.flag, tid, p.ready)) return false;
+            } else if (p.opts & PERSIST_OPT_BALANCE) setprio_rt((p.opts >> 4) & 3u);   // released on arrival
             if (p.nservice) {                                  // the column workgroup has published this pass's table
                 const double *tab = p.shtab + (size_t)((q - 1u) & 1u) * 4 * (a.ng - 2);
                 T *dst = reinterpret_cast<T *>(L.sh);
@@ -620,8 +632,10 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
             }
         }
         PSTAMP(q, 1);
-        for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
-        __syncthreads();
+        if (!try_pre) {                                        // (else the previous publish has zeroed them)
+            for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
+            __syncthreads();
+        }
     } else {
         if (p.opts & PERSIST_OPT_BALANCE) setprio_rt((p.opts >> 8) & 3u);
         PSTAMP(q, 1);
@@ -629,7 +643,6 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
     int wmin = INT_MAX, wmax = INT_MIN;
     const StageLds<T> SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
     // PREFETCH (persist_publish): lane 0 polls `ready` before the workgroup's last resident tile
-    const bool try_pre = NRES > 0 && p.nservice != 0 && (p.opts & PERSIST_OPT_PREFETCH) != 0;
     unsigned int polled = 0u;
     process_tiles<T, STAGE, SAT, FVEC, true, DIRECT, true, NRES, RL>(a, SL, cur, start, end, tid, wave, lane, wmin, wmax, &res,
                                                                      try_pre ? p.ready : nullptr, &polled);
@@ -724,6 +737,11 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? ((MSGW_EXP3 && NRES == 2) ? 
         // (with resident tiles: also leaves cg_rr of the initial state of the streamed tiles in memory)
         deposit_pass<T, FVEC, (NRES > 0 && NRES <= CGMEM_MAX_NRES && !SAT)>(a, SL, start, end, tid, wave, lane, start + (long long)NRES * TILE);
         persist_publish(p, L.rows, ncp, L.flag, tid, 0u);
+        // flavours with the pass-boundary prefetch: every later publish leaves the wave rows zeroed for the next pass
+        if (NRES > 0 && p.nservice != 0 && (p.opts & PERSIST_OPT_PREFETCH) != 0) {
+            for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
+            __syncthreads();
+        }
     }
     // resident tiles: everything a stage may read (stage 2 of the DIRECT variant reads the most); lanes
     // beyond the workgroup's rays hold inert values and are never deposited or stored
@@ -750,7 +768,7 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? ((MSGW_EXP3 && NRES == 2) ? 
     }
     const long long sstart = start + (long long)NRES * TILE;    // first streamed ray
     unsigned int q = 0;
-    bool pre = false;
+    int pre = 0;
     for (int step = 0; step < p.nsteps; ++step) {
         if (!persist_stage<T, 0, SAT, FVEC, DIRECT, NRES, RL>(p, L, q, sstart, end, tid, wave, lane, res, pre)) return;
         ++q;
