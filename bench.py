@@ -419,7 +419,7 @@ def main():
                                                "reduce chain, 9.2 us from the last row to the release, is close behind); the persistent kernel "
                                                "keeps the evolving ray state in registers, so the measured HBM traffic is well below the "
                                                "algorithmic bytes (DESIGN.md 6)",
-                                    "config5": "latency at 2 wavefronts per SIMD (PMC: VALU 48 % busy, waves waiting 57 % of their "
+                                    "config5": "latency at 2 wavefronts per SIMD (PMC: VALU 54 % busy, waves waiting 52 % of their "
                                                "cycles); the deposit of a dispersed packet (wavefronts whose rays span many levels)",
                                     "config2": "1e5 rays are 784 wavefronts for 1024 SIMDs, each issuing its ~200 FP64 instructions "
                                                "per ray-stage alone (PMC: VALU 41 % busy); the state never leaves the registers"

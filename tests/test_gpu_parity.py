@@ -466,21 +466,23 @@ def test_table_prefetch_is_bitwise_neutral(monkeypatch, n, flags, regtiles, dtyp
     """The early poll + shear-table prefetch at the pass boundary of the resident-tile flavours (persist_publish,
     MSGW_PREFETCH=0 | 1, on by default) changes WHEN a workgroup stages the next pass's table and zeroes its wave rows,
     never a value or a summation order: the states with and without it are bit for bit the same (resident tiles only,
-    resident + streamed tiles, relaunch variant, float32 rays)."""
+    resident + streamed tiles, relaunch variant, float32 rays); likewise the wave-priority balancing (MSGW_BALANCE)."""
     s, st = _random_case(n, 77, False, "uniform", True)
     st[0] = st[0] * 1e-3
     monkeypatch.setenv("MSGW_REGTILES", regtiles)
     outs = {}
-    for pre in ("1", "0"):
+    for pre, bal in (("1", "1"), ("0", "1"), ("1", "0")):     # (MSGW_BALANCE: wave priorities of a CU's two workgroups)
         monkeypatch.setenv("MSGW_PREFETCH", pre)
+        monkeypatch.setenv("MSGW_BALANCE", bal)
         p = make_prop(s, st, dtype=dtype)
         p.step(60.0, 1, flags)
         p.step(60.0, 7, flags)
-        outs[pre] = gpu_state(p, st)
+        outs[pre + bal] = gpu_state(p, st)
         assert p.counters()["persist_steps"] == 7
         p.close()
-    for a, b in zip(outs["1"], outs["0"]):
-        assert np.array_equal(np.asarray(a), np.asarray(b))
+    for other in ("01", "10"):
+        for a, b in zip(outs["11"], outs[other]):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), other
 
 
 @pytest.mark.parametrize("ngrid", [5, 6, 9])
