@@ -2,20 +2,24 @@
 """
 bench.py -- ray-steps/s of the MI355X ray-propagation path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|config2|config5] [--repeats R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3|config4|config2|config5] [--repeats R]
+                    [--rays-per-gpu M | --total-rays T]
 
 A "step" is one lprop.RK3 step (3 RHS stages incl. flux deposit and mean-flow update) of every resident ray.
 Workloads (BASELINE.json configs; synthetic Gaussian source spectrum of SURVEY 8d, inputs resident in HBM before the
 timed region):
 
-  config3 (default)  1e6 rays per GPU, interactive mean flow, float64                    280 B per ray-step
+  config3 (default at N = 1)  1e6 rays per GPU, interactive mean flow, float64            280 B per ray-step
+  config4 (default at N > 1)  1.25e6 rays per GPU (1e7 rays on 8 GPUs), otherwise config3  280 B per ray-step
   config2            1e5 rays per GPU, fixed background (pure propagation), float64       48 B per ray-step
   config5            1.25e6 rays per GPU, float32 state, online saturation + the
                      relaunch extension (alpha = 0.5), interactive mean flow              180 B per ray-step
 
 For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds `--rays-per-gpu` rays (weak
-scaling; N = 8 with 1.25e6 rays per GPU is config 4 / config 5) and the 2 x (ngrid-2) flux profile is summed over the
-ranks once per RK stage inside the C library (`config.parallelism` names the transport).
+scaling, the default: N = 8 with 1.25e6 rays per GPU is config 4 / config 5) or `--total-rays / N` rays (strong
+scaling: SURVEY 8d's "1, 2, 4 GPUs with the same total N" table; the line then says "scaling": "strong"), and the
+2 x (ngrid-2) flux profile is summed over the ranks once per RK stage inside the C library (`config.parallelism` names
+the transport).
 
 Timing: R repeats of the same experiment -- fresh initial state, W untimed warm-up steps, then EXACTLY K steps timed,
 bracketed by a barrier + synchronisation on both sides, MAX over the ranks; `value` and `ms_per_step` are the MEDIAN
@@ -38,6 +42,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "python-msgwam_amd"))
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# VALU issue peak: 1024 SIMDs, one wave64 VALU instruction per 4 clocks of the 2.4 GHz maximum clock (float64 FMA:
+# 78.6 TF = 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz, i.e. 16 lanes per clock per SIMD), in 1e9 wave-instructions/s
+VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 4
 DT = 120.0                      # raytracer.py:46
 
 WORKLOADS = {
@@ -45,6 +52,9 @@ WORKLOADS = {
     "config3": dict(bytes=280.0, dtype="f64", rays=1_000_000, alpha=0.01, sat=False, flags=0, kernel="k_rk3_persist",
                     text="config3: 1e6 rays/GPU, interactive mean flow (flux deposit + u,v update every RK stage), "
                          "synthetic Gaussian spectrum, fp64"),
+    "config4": dict(bytes=280.0, dtype="f64", rays=1_250_000, alpha=0.01, sat=False, flags=0, kernel="k_rk3_persist",
+                    text="config4: 1.25e6 rays/GPU (1e7 rays over 8 GPUs), interactive mean flow, flux profile summed over "
+                         "the ranks once per RK stage, synthetic Gaussian spectrum, fp64"),
     "config2": dict(bytes=48.0, dtype="f64", rays=100_000, alpha=0.01, sat=False, flags="fixed", kernel="k_ray_step_fixed",
                     text="config2: 1e5 rays/GPU, fixed background, pure propagation, fp64"),
     "config5": dict(bytes=180.0, dtype="f32", rays=1_250_000, alpha=0.5, sat=True, flags="relaunch", kernel="k_rk3_persist",
@@ -113,6 +123,28 @@ def cpu_baseline(wl, grid, uu, vv, budget_s=12.0):
             "vectorised_numpy_value": vec_rate, "c_port_value": c_rate}
 
 
+def kernel_src_digest():
+    """Digest of the device code's sources: profiles/traffic.json entries carry the digest they were measured at, so a
+    line can say when its committed counter figures predate a kernel change (`traffic_stale`)."""
+    import glob
+    import hashlib
+    h = hashlib.blake2b(digest_size=8)
+    d = os.path.join(ROOT, "python-msgwam_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def load_counter_table():
+    """profiles/traffic.json: per kernel flavour the HBM bytes (FETCH_SIZE doubled + WRITE_SIZE) and the wave-level
+    VALU instructions (SQ_INSTS_VALU) per ray-step from committed rocprofv3 --pmc passes (tools/make_counter_table.py)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))), None
+    except Exception as e:      # noqa: BLE001
+        return None, str(e)
+
+
 def copy_ceiling(torch, nbytes=1 << 30, reps=10):
     """Measured streaming ceiling of this GPU: device-to-device copy of a buffer far larger than the 256 MiB
     Infinity Cache, read + written bytes over the HIP-event time (SURVEY 8d asks for it beside the 8 TB/s spec)."""
@@ -139,8 +171,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=0, help="timed repeats of K steps (0 = until the timed region is >= 50 ms, at least 5)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS) + sorted(ALIASES), default="config3")
-    ap.add_argument("--rays-per-gpu", type=int, default=0, help="0 = the workload's BASELINE size")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + sorted(ALIASES), default=None,
+                    help="default: config3 at N = 1 (the configuration BASELINE's metric is quoted on), config4 at N > 1")
+    ap.add_argument("--rays-per-gpu", type=int, default=0, help="0 = the workload's BASELINE size (weak scaling)")
+    ap.add_argument("--total-rays", type=int, default=0,
+                    help="strong scaling: this many rays in total, divided evenly over the N ranks (SURVEY 8d: the "
+                         "same-total-N table of config 4)")
+    ap.add_argument("--no-streamed-leg", action="store_true",
+                    help="skip the all-rays-streamed measurement (MSGW_REGTILES=0) behind roofline.hbm_streamed")
     ap.add_argument("--ngrid", type=int, default=101)
     ap.add_argument("--blocks-per-cu", type=int, default=int(os.environ.get("MSGW_BLOCKS_PER_CU", 4)))
     ap.add_argument("--graph-steps", type=int, default=int(os.environ.get("MSGW_GRAPH_STEPS", 4)))
@@ -162,11 +200,15 @@ def main():
     ap.add_argument("--kernel-events", choices=["separate", "same", "none"], default="same",
                     help="where the per-launch HIP-event timing of the dominant kernel is taken")
     args = ap.parse_args()
-    wl = ALIASES.get(args.workload, args.workload)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    wl = args.workload or ("config3" if max(world, args.gpus) == 1 else "config4")
+    wl = ALIASES.get(wl, wl)
     W = WORKLOADS[wl]
+    if args.total_rays and args.rays_per_gpu:
+        raise SystemExit("--total-rays and --rays-per-gpu exclude each other")
+    strong = args.total_rays > 0
     rays_per_gpu = args.rays_per_gpu or W["rays"]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
@@ -217,9 +259,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return bool(t.item() > 0.5)
 
-    def measure(rays, steps, warmup, kernel_events, repeats, pre_steps=0):
-        """`repeats` timed regions of `steps` RK3 steps of `rays` rays per rank, state resident."""
-        n_total = rays * world
+    def measure(rays, steps, warmup, kernel_events, repeats, pre_steps=0, total=0):
+        """`repeats` timed regions of `steps` RK3 steps of `rays` rays per rank (or `total` rays over all ranks),
+        state resident."""
+        n_total = total or rays * world
         lo, hi = shard_bounds(n_total, world, rank)
         sp = gaussian_spectrum(n_total, grids, lprop.rhobar, alpha=W["alpha"], start=lo, stop=hi)
         n_local = hi - lo
@@ -338,7 +381,7 @@ def main():
         if env:
             os.environ.update(env)
         try:
-            m = measure(rays_per_gpu, args.steps, args.warmup, args.kernel_events, args.repeats)
+            m = measure(rays_per_gpu, args.steps, args.warmup, args.kernel_events, args.repeats, total=args.total_rays)
             break
         except ExchangeFailed as e:
             fell_back.append(str(e))
@@ -349,87 +392,142 @@ def main():
     n_total, n_local, kern_ms, c1, finite = m["n_total"], m["n_local"], m["kern_ms"], m["counters"], m["finite"]
     walls = np.array(m["walls"])
     wall = float(np.median(walls))
-    extra, late = None, None
+    extra, late, streamed = None, None, None
     coupled = W["flags"] != "fixed"
     if world == 1 and coupled and not args.no_size_sweep:
         ks = max(args.steps // 4, 20)
         big = measure(4 * rays_per_gpu, ks, max(args.warmup // 4, 5), "none", 3)
         v = big["n_total"] * ks / float(np.median(big["walls"]))
         extra = {"rays_per_gpu": big["n_total"], "value": v,
-                 "whole_job_hbm_frac": v * W["bytes"] / 1e9 / HBM_PEAK_GBS,
+                 "effective_algorithmic_frac_of_hbm_peak": v * W["bytes"] / 1e9 / HBM_PEAK_GBS,
                  "note": "same workload at 4x the rays: the streamed working set no longer fits the 256 MiB Infinity Cache"}
         lt = measure(rays_per_gpu, args.steps, args.warmup, "none", 0, pre_steps=args.late_steps)
         lw = np.array(lt["walls"])
         late = {"pre_steps": args.late_steps + args.warmup, "value": lt["n_total"] * args.steps / float(np.median(lw)),
                 "ms_per_step": float(np.median(lw)) / args.steps * 1e3, "state_finite": lt["finite"],
                 "note": "same workload measured after the packet has dispersed over many levels (deposit spans widen)"}
+    if world == 1 and coupled and not args.no_streamed_leg and c1.get("persist_resident_tiles", 0) > 0 \
+            and not args.force_collective:
+        # the HBM-honest figure, taken in the same run: the same workload with EVERY ray streamed through HBM each RK
+        # stage (MSGW_REGTILES=0: no register-resident tiles), whose counter traffic equals the algorithmic bytes
+        old = os.environ.get("MSGW_REGTILES")
+        os.environ["MSGW_REGTILES"] = "0"
+        try:
+            sm = measure(rays_per_gpu, args.steps, args.warmup, "same", 3)
+        finally:
+            if old is None:
+                os.environ.pop("MSGW_REGTILES", None)
+            else:
+                os.environ["MSGW_REGTILES"] = old
+        streamed = sm
 
     if rank == 0:
         value = n_total * args.steps / wall
         bps = W["bytes"]
         persist_steps = c1.get("persist_steps", 0)
-        fused_note = None
-        if persist_steps and wl == "config2":
-            # independent rays: all steps of the call run in ONE launch with rr, mm in registers, so the state
-            # touches HBM once per launch; SURVEY 8d counts 48 B per ray-step (state materialised every step),
-            # which this kernel does not move -- the HBM roofline does not bound it (FP64 VALU does)
+        nres = c1.get("persist_resident_tiles", 0)
+        narrow = c1.get("fixed_narrow", 0)
+        table, table_err = load_counter_table()
+        digest = kernel_src_digest()
+
+        def counters_for(key):
+            t = table.get(key) if table else None
+            if not isinstance(t, dict):
+                return None, f"no PMC measurement committed for {key} (profiles/traffic.json)" + (f": {table_err}" if table_err else "")
+            return t, None
+
+        def hbm_traffic(t, rays, steps_per_launch):
+            if t is None:
+                return None
+            if "bytes_per_ray_launch" in t:
+                return t["bytes_per_ray_launch"] * rays
+            if "bytes_per_ray_step" in t:
+                return t["bytes_per_ray_step"] * rays * steps_per_launch
+            return None
+
+        if persist_steps:        # one launch covers persist_steps RK3 steps (persistent coupled kernel / fused fixed kernel)
             per_launch_bytes = bps * persist_steps * n_local
             kernel_name = W["kernel"]
-            fused_note = (f"SURVEY 8d accounting (48 B per ray-step: state materialised once per step) x rays x the "
-                          f"{persist_steps} steps of one launch; the kernel fuses those steps in registers and moves "
-                          "48 B per ray per LAUNCH, so this is an effective rate -- the bound is the FP64 issue rate "
-                          "(PMC: VALU 41 % busy at 1e5 rays, one wavefront per SIMD on 784 of 1024 SIMDs; "
-                          "profiles/r02_config2_summary.md)")
-        elif persist_steps:      # one persistent launch covers persist_steps RK3 steps (3 stages each)
-            per_launch_bytes = bps * persist_steps * n_local
-            kernel_name = "k_rk3_persist"
+            steps_per_launch = persist_steps
         else:
             per_launch_bytes = bps / 3 * n_local
             kernel_name = "k_ray_stage"
+            steps_per_launch = 1.0 / 3
+        key = f"{wl if wl != 'config4' else 'config3'}:{W['dtype']}:{n_local}:res{nres}" + (":narrow" if narrow else "")
         roofline = None
         if kern_ms:
-            achieved = per_launch_bytes / (kern_ms * 1e-3) / 1e9
-            # HBM bytes actually moved per launch: committed rocprofv3 PMC result (profiles/traffic.json, separate
-            # --pmc passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), keyed by workload:dtype:rays:resident tiles
-            traffic, traffic_note = None, None
-            key = f"{wl}:{W['dtype']}:{n_local}:res{c1.get('persist_resident_tiles', 0)}"
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            try:
-                t = json.load(open(tpath)).get(key)
-                if isinstance(t, dict) and persist_steps and "bytes_per_ray_launch" in t:
-                    traffic = t["bytes_per_ray_launch"] * n_local          # steps fused in registers: once per launch
-                    traffic_note = t.get("source")
-                elif isinstance(t, dict) and persist_steps:
-                    traffic = t["bytes_per_ray_step"] * n_local * persist_steps
-                    traffic_note = t.get("source")
-                else:
-                    traffic_note = f"no PMC measurement committed for {key} on this kernel path (profiles/traffic.json)"
-            except Exception as e:      # noqa: BLE001
-                traffic_note = f"profiles/traffic.json unreadable: {e}"
-            roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "achieved_is": "ALGORITHMIC bytes (SURVEY 8d words per ray-step x rays x steps of one launch) / "
-                                       "the launch's HIP-event duration -- an effective rate: a persistent kernel that "
-                                       "keeps tiles in registers moves fewer bytes than that (see traffic)",
-                        "traffic": traffic, "traffic_source": traffic_note,
-                        "hbm_counter_gbs": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9,
-                        "hbm_counter_frac": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "limiter": {"config3": "dependent LDS / memory round trips inside the tile body at 2 wavefronts per SIMD, and the younger of a "
-                                               "CU's two workgroups (its loop -- table 1.3 + tiles 8.2 + publish 1.3 us -- is the pass period; the "
-                                               "reduce chain, 9.2 us from the last row to the release, is close behind); the persistent kernel "
-                                               "keeps the evolving ray state in registers, so the measured HBM traffic is well below the "
-                                               "algorithmic bytes (DESIGN.md 6)",
-                                    "config5": "latency at 2 wavefronts per SIMD (PMC: VALU 54 % busy, waves waiting 52 % of their "
-                                               "cycles); the deposit of a dispersed packet (wavefronts whose rays span many levels)",
-                                    "config2": "1e5 rays are 784 wavefronts for 1024 SIMDs, each issuing its ~200 FP64 instructions "
-                                               "per ray-stage alone (PMC: VALU 41 % busy); the state never leaves the registers"
-                                    }.get(wl) if persist_steps else None,
-                        "kernel_ms_avg": kern_ms,
-                        "algorithmic_bytes_per_launch": per_launch_bytes,
-                        "events": "HIP events around every launch, " +
-                                  ("inside the timed region (median over the repeats)" if same else "second pass of the same K steps")}
-            if fused_note:
-                roofline["note"] = fused_note
+            ksec = kern_ms * 1e-3
+            eff = per_launch_bytes / ksec / 1e9
+            t, t_note = counters_for(key)
+            traffic = hbm_traffic(t, n_local, steps_per_launch if persist_steps else 1.0 / 3)
+            stale = bool(t is not None and t.get("src_digest") not in (None, digest))
+            issue_bound = bool(persist_steps) and (wl == "config2" or nres > 0)
+            common = {
+                "kernel": kernel_name, "kernel_ms_avg": kern_ms,
+                "traffic": traffic, "traffic_source": (t or {}).get("source", t_note),
+                "traffic_stale": stale,
+                "traffic_note": "HBM bytes per launch by the PMC counters of the committed rocprofv3 passes (separate --pmc "
+                                "runs, FETCH_SIZE doubled + WRITE_SIZE, x1024; MI355X_MICROARCH.md) scaled to this launch's "
+                                "rays x steps; `traffic_stale`: the kernel sources have changed since those passes",
+                "hbm_counter_gbs": None if traffic is None else traffic / ksec / 1e9,
+                "hbm_counter_frac": None if traffic is None else traffic / ksec / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": per_launch_bytes,
+                "effective_algorithmic_gbs": eff,
+                "effective_algorithmic_frac_of_hbm_peak": eff / HBM_PEAK_GBS,
+                "effective_algorithmic_is": "SURVEY 8d words per ray-step x rays x steps of one launch / the launch's HIP-event "
+                                            "duration: an EFFECTIVE rate, not a utilisation (a kernel that keeps the evolving "
+                                            "state in registers moves fewer bytes than that, so it can exceed the HBM peak)",
+                "events": "HIP events around every launch, " +
+                          ("inside the timed region (median over the repeats)" if same else "second pass of the same K steps"),
+            }
+            if issue_bound:
+                vi = None if t is None else t.get("valu_wave_insts_per_ray_step")
+                ach = None if vi is None else vi * n_local * persist_steps / ksec / 1e9
+                roofline = {"bound": "valu_issue", "achieved": ach, "peak": VALU_ISSUE_PEAK_GINST,
+                            "unit": "1e9 wave64 VALU instructions/s",
+                            "frac": None if ach is None else ach / VALU_ISSUE_PEAK_GINST,
+                            "achieved_is": "wave-level VALU instructions of one launch (SQ_INSTS_VALU of the committed rocprofv3 "
+                                           "pass for this kernel flavour, per ray-step, x this launch's rays x steps) / the "
+                                           "launch's HIP-event duration measured in this run; peak = 1024 SIMDs x 2.4 GHz / 4 "
+                                           "clocks per wave64 instruction",
+                            "why_not_hbm": ("the fused kernel keeps rr, mm in registers for all steps of a launch"
+                                            if wl == "config2" else
+                                            "the persistent kernel keeps the evolving ray state in registers for the whole "
+                                            "launch: HBM carries only the static factors (see traffic / hbm_counter_frac), so "
+                                            "the HBM roofline does not bound it; the all-rays-streamed flavour of the same "
+                                            "kernel, measured in this run, is under hbm_streamed"),
+                            **common}
+            else:
+                roofline = {"bound": "hbm", "achieved": eff, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eff / HBM_PEAK_GBS,
+                            "achieved_is": "ALGORITHMIC bytes (SURVEY 8d) of one launch / its HIP-event duration; every ray "
+                                           "streams through HBM once per RK stage on this path", **common}
+            roofline["limiter"] = {
+                "config3": "VALU issue at 2 wavefronts per SIMD (dependent LDS / memory round trips inside the tile body) and "
+                           "the pass hand-off: the younger of a CU's two workgroups sets the pass period (DESIGN.md 6)",
+                "config4": "as config3, plus the rank sum on the reduce chain (DESIGN.md 5a)",
+                "config5": "latency at 2 wavefronts per SIMD; the deposit of a dispersed packet (wavefronts whose rays span "
+                           "many levels)",
+                "config2": "issue of dependent float64 chains (3 IEEE divisions + 1 square root per ray-stage); at 1e5 rays "
+                           "the chip holds 1.5 wavefronts per SIMD (one ray per lane), so the integer number of wavefronts "
+                           "per SIMD is part of the bound (DESIGN.md 4, K1f)"}.get(wl) if persist_steps else None
+            if streamed is not None and streamed["kern_ms"]:
+                sc = streamed["counters"]
+                s_sec = streamed["kern_ms"] * 1e-3
+                s_bytes = bps * sc.get("persist_steps", 0) * streamed["n_local"]
+                s_key = f"{wl if wl != 'config4' else 'config3'}:{W['dtype']}:{streamed['n_local']}:res0"
+                st_, _ = counters_for(s_key)
+                s_tr = hbm_traffic(st_, streamed["n_local"], sc.get("persist_steps", 0))
+                s_wall = float(np.median(streamed["walls"]))
+                roofline["hbm_streamed"] = {
+                    "what": "the same workload with MSGW_REGTILES=0 (every ray streamed through HBM once per RK stage), "
+                            "measured in this run: the HBM-honest yardstick of this path",
+                    "bound": "hbm", "achieved": s_bytes / s_sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": s_bytes / s_sec / 1e9 / HBM_PEAK_GBS, "kernel_ms_avg": streamed["kern_ms"],
+                    "ms_per_step": s_wall / streamed["steps"] * 1e3,
+                    "value": streamed["n_total"] * streamed["steps"] / s_wall,
+                    "register_resident_tiles_per_workgroup": sc.get("persist_resident_tiles", 0),
+                    "traffic": s_tr, "traffic_stale": bool(st_ is not None and st_.get("src_digest") not in (None, digest)),
+                    "hbm_counter_frac": None if s_tr is None else s_tr / s_sec / 1e9 / HBM_PEAK_GBS}
             try:
                 roofline["copy_ceiling_gbs"] = copy_ceiling(torch)
             except Exception as e:      # noqa: BLE001
@@ -452,16 +550,23 @@ def main():
             "ms_per_step": wall / args.steps * 1e3,
             "ms_per_step_min": float(walls.min()) / args.steps * 1e3,
             "ms_per_step_max": float(walls.max()) / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": W["dtype"], "data": "synthetic",
             "config": {"workload": W["text"],
-                       "rays_total": n_total, "rays_per_gpu": rays_per_gpu, "ngrid": args.ngrid,
+                       "rays_total": n_total, "rays_per_gpu": n_total // world if strong else rays_per_gpu,
+                       "ngrid": args.ngrid,
                        "dt": DT, "parallelism": par, "transport": transport,
                        **({"transport_fallbacks": fell_back} if fell_back else {}),
-                       "graph_steps": c1["graph_steps"], "persist_steps": persist_steps, "blocks": c1["blocks"],
-                       "register_resident_tiles_per_workgroup": c1.get("persist_resident_tiles", 0),
+                       "graph_steps": c1["graph_steps"], "persist_steps": persist_steps,
+                       "launch_workgroups": c1.get("launch_grid", 0),
+                       "launch_ray_workgroups": c1.get("launch_ray_workgroups", 0),
+                       "launch_reducer_workgroups": c1.get("launch_reducers", 0),
+                       "per_stage_kernel_workgroups": c1["blocks"],
+                       "register_resident_tiles_per_workgroup": nres,
+                       **({"one_ray_per_lane": bool(narrow)} if wl == "config2" else {}),
+                       "kernel_src_digest": digest,
                        "timing": "median of `repeats` identical experiments (fresh state, `warmup` steps, then `steps` steps timed)"},
-            "whole_job_hbm_frac": value * bps / 1e9 / (HBM_PEAK_GBS * world),
+            "effective_algorithmic_frac_of_hbm_peak": value * bps / 1e9 / (HBM_PEAK_GBS * world),
             "state_finite": finite,
             "roofline": roofline,
         }

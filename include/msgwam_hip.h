@@ -37,7 +37,7 @@ extern "C" {
 
 typedef struct msgw_ctx msgw_ctx;
 
-#define MSGW_ABI_VERSION 2
+#define MSGW_ABI_VERSION 3
 
 /* error codes */
 #define MSGW_OK            0
@@ -88,6 +88,15 @@ typedef struct {
     int32_t elem_bytes;          /* bytes per element of the resident ray state: 8 (float64) or 4 (float32) */
     int32_t transport;           /* MSGW_TRANSPORT_* of the communicator                         */
     int32_t tenants;             /* ranks of the communicator that share this rank's device (1 in production) */
+    /* ABI 3 */
+    int32_t launch_grid;         /* workgroups of the LAST ray-kernel launch (persistent kernel: ray workgroups + reducers
+                                    + column workgroup; `blocks` is the per-stage kernels' geometry) */
+    int32_t launch_ray_workgroups; /* of those, the workgroups that own rays */
+    int32_t launch_reducers;     /* persistent kernel: reducer workgroups of the last launch (0: the last arriver reduces) */
+    int32_t fixed_narrow;        /* fixed-background kernel: 1 = one ray per lane, one wavefront per workgroup */
+    double  algorithmic_bytes_total; /* SURVEY 8d bytes moved since create: words per ray-step of the path taken (35 coupled,
+                                    45 with online saturation, 6 fixed background; 71 HPROP, 63 N(z)) x elem_bytes x rays
+                                    x steps -- the yardstick of the roofline, not a hardware counter */
 } msgw_counters_t;
 
 /* HPROP on: slots 1 and 2 (lam, phi) of the rays uploaded by the last msgw_upload_rays (same n). */
@@ -166,13 +175,15 @@ int msgw_rhs(msgw_ctx *ctx, double dt, unsigned flags,
 /* lprop.wave_projection(..., grid, var) (lib/libprop.py:92-219) of the resident
  * rays on an arbitrary uniform grid G [nG].  var 0, 1, 2 (cell centres): out is
  * [2][nG-1] for var 0 and [nG-1] otherwise (raytracer.py:213, :227); var 3, 4
- * (interfaces, :199-219): [nG] and [2][nG]. */
+ * (interfaces, :199-219): [nG] and [2][nG].  With an N(z) column the group velocity uses N at the ray centre rr. */
 int msgw_project(msgw_ctx *ctx, int var, const double *G, int nG, double *out);
 
 /* lprop.wave_projection(dens, lam, phi, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk,
  * dll, dmm, grid, var) (lib/libprop.py:92-197) on caller-supplied host arrays
  * [n each]; fray[i] = 2*ROT_EARTH*sin(phi[i]); lam is unused by the reference.
- * Independent of the resident state (only the stream and scratch are used). */
+ * Independent of the resident state (only the stream and scratch are used).
+ * bvf: the scalar N of model_config (:139-144 -> :380); EXTENSION: NaN = the context's N(z) column
+ * (msgw_set_bvf_column + msgw_set_column), np.interp'ed to the ray centre .5 * (rr_low + rr_up). */
 int msgw_project_arrays(msgw_ctx *ctx, int64_t n, int var, double bvf,
                         const double *dens, const double *rr_low, const double *rr_up,
                         const double *kk, const double *ll, const double *mm_low,
@@ -184,7 +195,9 @@ int msgw_project_arrays(msgw_ctx *ctx, int64_t n, int var, double bvf,
  * mm_center, mm_center_st, direct) (lib/libprop.py:561-615) on caller arrays,
  * with statics dkk, dll, rr_mm_area (:585-587) passed explicitly; uses the
  * resident config (bvf, f0, kappa) and column (grids, rhobar).  out [n]:
- * the saturated density (direct != 0, :606-610) or its tendency (:612-615). */
+ * the saturated density (direct != 0, :606-610) or its tendency (:612-615).
+ * With an N(z) column (msgw_set_bvf_column; extension) omega uses N at rr_center and the cap N at the projected height
+ * rr_center + rr_center_st * dt, as in the stage kernels. */
 int msgw_saturation(msgw_ctx *ctx, int64_t n, double dt, int direct,
                     const double *dens, const double *rr_center, const double *rr_center_st,
                     const double *drr, const double *drr_st, const double *kk, const double *ll,

@@ -52,12 +52,14 @@ const void *stage_kernel_impl<real_t, MSGW_STAGE>(bool sat, bool fvec, bool depo
 
 #if MSGW_STAGE == 3
 template <>
-const void *fixed_kernel<real_t>(bool sat, bool fvec, bool direct)
+const void *fixed_kernel<real_t>(bool sat, bool fvec, bool direct, bool narrow)
 {
-    return bsel(sat, [&](auto SAT) { return bsel(fvec, [&](auto FVEC) { return bsel(direct, [&](auto DIR) -> const void * {
-        if constexpr (decltype(SAT)::value && decltype(DIR)::value) return nullptr;
-        else return KPTR(k_ray_step_fixed<real_t, decltype(SAT)::value, decltype(FVEC)::value, decltype(DIR)::value>);
-    }); }); });
+    return bsel(sat, [&](auto SAT) { return bsel(fvec, [&](auto FVEC) { return bsel(direct, [&](auto DIR) {
+        return bsel(narrow, [&](auto NAR) -> const void * {
+            if constexpr (decltype(SAT)::value && decltype(DIR)::value) return nullptr;
+            else return KPTR(k_ray_step_fixed<real_t, decltype(SAT)::value, decltype(FVEC)::value, decltype(DIR)::value,
+                                              decltype(NAR)::value>);
+        }); }); }); });
 }
 template <>
 const void *deposit_only_kernel<real_t>(bool fvec)

@@ -31,7 +31,7 @@ inline const void *stage_kernel(int stage, bool sat, bool fvec, bool deposit, bo
 }
 
 // defined next to the STAGE = 3 (probe) kernels of each ray type
-template <typename T> const void *fixed_kernel(bool sat, bool fvec, bool direct);     // k_ray_step_fixed
+template <typename T> const void *fixed_kernel(bool sat, bool fvec, bool direct, bool narrow = false);   // k_ray_step_fixed
 template <typename T> const void *deposit_only_kernel(bool fvec);                    // k_deposit_only
 template <typename T> const void *project_kernel(int np, bool fvec);                 // k_project on resident rays
 template <typename T> const void *fill_kernel();                                     // k_fill_range

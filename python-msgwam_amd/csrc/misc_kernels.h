@@ -20,9 +20,15 @@ __global__ void __launch_bounds__(BLOCK) k_saturation(const SatArgs a)
     const double rho_f = interp_eval(rr_f, br, a.rhobar[br.j], a.slrho[min(br.j, a.nc - 2)]);   // :595
     const double kh2 = a.kk[i] * a.kk[i] + a.ll[i] * a.ll[i];
     const double m2 = a.mm[i] * a.mm[i];
-    const double omh = sqrt((a.bvf2 * kh2 + a.f0sq * m2) / (kh2 + m2));          // :597
+    double n2_c = a.bvf2, n2_f = a.bvf2;
+    if (a.bvfcol) {                                                  // EXTENSION: N(z) column
+        const double N_c = interp_global(a.rr[i], a.grids, a.bvfcol, a.nc, a.gs0, a.gs_last, a.inv_dzs);
+        const double N_f = interp_global(rr_f, a.grids, a.bvfcol, a.nc, a.gs0, a.gs_last, a.inv_dzs);
+        n2_c = N_c * N_c; n2_f = N_f * N_f;
+    }
+    const double omh = sqrt((n2_c * kh2 + a.f0sq * m2) / (kh2 + m2));            // :597 (N at rr_center)
     const double pv = a.dkk[i] * a.dll[i] * dmm_f;                   // :599
-    const double maxd = sat_cap(a.sat_c, rho_f, omh, a.bvf2, mm_f, a.f0sq);      // :601
+    const double maxd = sat_cap(a.sat_c, rho_f, omh, n2_f, mm_f, a.f0sq);        // :601 (NN at rr_final)
     const double d = a.dens[i];
     const bool hit = maxd < d * pv;                                  // :604
     if (a.direct) a.out[i] = hit ? maxd : d;                         // :606-610

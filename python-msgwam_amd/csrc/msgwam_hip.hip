@@ -173,6 +173,8 @@ struct msgw_ctx {
     int service = 1;                 // reducer workgroups beside the workers (MSGW_SERVICE=0: last arriver reduces)
     int balance = 1;                 // laggard workgroups of a CU raise their wave priority (MSGW_BALANCE=0 | 1)
     int prefetch = 1;                // early poll + table prefetch at the pass boundary of the resident-tile flavours (MSGW_PREFETCH=0 | 1)
+    int fixed_narrow_force = -1;         // MSGW_FIXED_NARROW=0 | 1 (diagnostic), read when the context is created
+    int64_t fixed_narrow_max = 400000;   // fixed background: ray counts up to this run one ray per lane (launch_fixed)
     int regtiles = 4;                // most register-resident tiles per workgroup in the persistent kernel (MSGW_REGTILES=0 | 2 | 4)
     double *grp_rows2 = nullptr;     // [2][PERSIST_GROUPS][ncols]
     unsigned int *pdone = nullptr;   // PDONE_WORDS: [0] ready, [32..33] done2, [64] final rows, [96] rank rows, [128..] group tickets
@@ -535,6 +537,7 @@ int launch_stage(msgw_ctx *c, int stage, const StageArgsT<T> &a, int mode, bool 
     if (c->ng - 2 > 128) form = FORM_TALL;             // tall columns: per-level sums stay in LDS (NH = 0)
     else if (c->lagchain) form = FORM_LAG;             // lagged chain: deposit of the produced state, group rows by parity
     else if (c->groupred) form = FORM_GROUP;           // fused chain: first-level flux reduction inside the kernel
+    c->cnt.launch_grid = c->cnt.launch_ray_workgroups = c->blocks; c->cnt.launch_reducers = 0; c->cnt.fixed_narrow = 0;
     return launch_struct(c, stage_kernel<T>(stage, sat, c->fvec, true, direct, form, rl), c->blocks, BLOCK,
                          stage_lds_bytes(c), a, nullptr, timed);
 }
@@ -547,11 +550,33 @@ int launch_probe(msgw_ctx *c, const StageArgsT<T> &a, bool sat, bool deposit)
                          stage_lds_bytes(c), a);
 }
 
+// Fixed background (k_ray_step_fixed): independent rays, bound by the issue of dependent float64 chains.  Below
+// `fixed_narrow_max` rays the NARROW form runs -- one wavefront per workgroup, one ray per lane -- so that 1e5 rays
+// (BASELINE config 2) put 1563 wavefronts on all 1024 SIMDs instead of 784 two-ray wavefronts on 784 of them.
+// MSGW_FIXED_NARROW=0 | 1 forces a form (diagnostic).
 template <typename T>
-int launch_fixed(msgw_ctx *c, const StageArgsT<T> &a, int mode, bool timed)
+int launch_fixed(msgw_ctx *c, StageArgsT<T> a, int mode, bool timed)
 {
-    return launch_struct(c, fixed_kernel<T>(mode == 1, c->fvec, mode == 2), c->blocks, BLOCK, stage_lds_bytes(c), a,
-                         nullptr, timed);
+    const bool narrow = c->fixed_narrow_force >= 0 ? c->fixed_narrow_force != 0 : c->n <= c->fixed_narrow_max;
+    // tables only (the kernel deposits nothing): [sh][rho2][xg][gs] in the ray type (+ the float64 grid copy stage_xg
+    // writes for float32 rays)
+    const int ni = c->ng - 2, nc = c->ng - 1;
+    const size_t lds = ((c->esz * (size_t)(5 * ni + 3 * nc) + 15) & ~(size_t)15) + (c->f32 ? sizeof(double) * ni : 0) + 16;
+    unsigned grid = (unsigned)c->blocks, block = BLOCK;
+    if (narrow) {
+        const int64_t ntiles = (c->n + 63) / 64;
+        const int64_t maxb = (int64_t)c->ncu * 4 * 8;            // 8 wavefronts per SIMD at most
+        int64_t tpb = (ntiles + maxb - 1) / maxb;
+        if (tpb < 1) tpb = 1;
+        a.tiles_per_block = (int)tpb;
+        a.rays_per_block = tpb * 64;
+        grid = (unsigned)std::max<int64_t>((ntiles + tpb - 1) / tpb, 1);
+        block = 64;
+    }
+    c->cnt.fixed_narrow = narrow ? 1 : 0;
+    c->cnt.launch_grid = c->cnt.launch_ray_workgroups = (int)grid;
+    c->cnt.launch_reducers = 0;
+    return launch_struct(c, fixed_kernel<T>(mode == 1, c->fvec, mode == 2, narrow), grid, block, lds, a, nullptr, timed);
 }
 
 int launch_column(msgw_ctx *c, int stage, int mode, const ColArgs &a, hipStream_t stream = nullptr)
@@ -773,6 +798,7 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     c->status_armed = true;
     c->cnt.persist_resident_tiles = pl.nres;
     c->cnt.persist_steps = count;
+    c->cnt.launch_grid = pl.grid; c->cnt.launch_ray_workgroups = pl.blocks; c->cnt.launch_reducers = pl.nservice;
     if (multi) c->xch_seq += 3ull * (unsigned long long)count;   // fluxes 0 .. 3*count-1 were exchanged (strictly alternating slots)
     return MSGW_OK;
 }
@@ -1142,6 +1168,10 @@ int project_resident(msgw_ctx *c, int var, const double *G, int nG, double *out)
     a.bvf2 = (T)std::pow(c->bvf, 2.0); a.f_uni = (T)c->f_uni; a.dz = (T)(G[1] - G[0]);
     a.cdz = T(1) / a.dz; a.mk_ok = markstein_ok(a.dz);
     a.r = ray_ptrs<T>(c);
+    if (c->nz) {                                               // N(z) column (float64 contexts): N at the ray centre rr
+        a.bvfcol = c->bvfcol; a.grids = c->grids; a.nc = c->ng - 1;
+        a.gs0 = c->gs0; a.gs_last = c->gs_last; a.inv_dzs = 1.0 / c->dzs;
+    }
     const int np = (var == 0 || var == 4) ? 2 : 1;
     return run_projection(c, a, project_kernel<T>(np, c->fvec), Real<T>::TILE, np, G, nG, out);
 }
@@ -1220,6 +1250,7 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     c->cnt.nranks = 1;
     c->cnt.elem_bytes = (int32_t)c->esz;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
+    if (const char *e = std::getenv("MSGW_FIXED_NARROW")) c->fixed_narrow_force = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_BALANCE")) c->balance = std::atoi(e);
     if (const char *e = std::getenv("MSGW_PREFETCH")) c->prefetch = std::atoi(e) ? 1 : 0;
@@ -1447,15 +1478,24 @@ int msgw_set_bvf_column(msgw_ctx *c, const double *bvf)
     if (c->f32) return fail(c, MSGW_ERR_UNSUP, "the N(z) column extension is float64 only");
     const size_t nc = (size_t)c->ng - 1;
     if (!c->bvfcol) {
+        // allocate into locals and commit only when everything is there: a failed call leaves the context as it was
         const size_t padded = (((size_t)c->cap + c->tile - 1) / c->tile + 1) * c->tile;
-        HIPCHK(c, hipMalloc(&c->bvfcol, nc * sizeof(double)));
-        double **np_[] = {&c->nz_q_drr, &c->nz_q_dmm, &c->nz_dkdl, &c->nz_area};
-        for (double **p : np_) {
-            HIPCHK(c, hipMalloc(p, padded * sizeof(double)));
-            c->ray_bufs.push_back(*p);
-            HIPCHK(c, hipMemsetAsync(*p, 0, padded * sizeof(double), c->stream));
+        double *col = nullptr, *ray[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool ok = hipMalloc(&col, nc * sizeof(double)) == hipSuccess;
+        for (int i = 0; i < 4 && ok; ++i)
+            ok = hipMalloc(&ray[i], padded * sizeof(double)) == hipSuccess &&
+                 hipMemsetAsync(ray[i], 0, padded * sizeof(double), c->stream) == hipSuccess;
+        if (!ok) {
+            (void)hipStreamSynchronize(c->stream);
+            for (double *p : ray) if (p) (void)hipFree(p);
+            if (col) (void)hipFree(col);
+            (void)hipGetLastError();
+            return fail(c, MSGW_ERR_HIP, "hipMalloc of the N(z) column buffers failed");
         }
-        c->ray_bufs.push_back(c->bvfcol);
+        c->nz_q_drr = ray[0]; c->nz_q_dmm = ray[1]; c->nz_dkdl = ray[2]; c->nz_area = ray[3];
+        for (double *p : ray) c->ray_bufs.push_back(p);
+        c->bvfcol = col;
+        c->ray_bufs.push_back(col);
     }
     HIPCHK(c, hipMemcpyAsync(c->bvfcol, bvf, nc * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1532,6 +1572,7 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
         if (int rc = enqueue_steps_hprop(c, dt, gflags, nsteps)) return rc;
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
+        c->cnt.algorithmic_bytes_total += 71.0 * 8.0 * (double)c->n * nsteps;
         return MSGW_OK;
     }
     if (c->nz) {                                               // N(z) column extension: its own per-stage chain
@@ -1542,6 +1583,7 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
         if (int rc = enqueue_steps_nz(c, dt, gflags, nsteps)) return rc;
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
+        c->cnt.algorithmic_bytes_total += 63.0 * 8.0 * (double)c->n * nsteps;
         return MSGW_OK;
     }
     if (int rc = c->f32 ? step_impl<float>(c, dt, nsteps, gflags, eager, time_kernels)
@@ -1549,6 +1591,9 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
         return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
+    // SURVEY 8d words per ray-step: fixed background 6, coupled 35, coupled + online saturation 45
+    c->cnt.algorithmic_bytes_total += ((flags & MSGW_FIXED_BACKGROUND) ? 6.0 : (c->sat_online ? 45.0 : 35.0)) *
+                                      (double)c->esz * (double)c->n * nsteps;
     c->cnt.graph_steps = c->gexec ? c->g_steps : 0;
     if (time_kernels) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1614,6 +1659,9 @@ int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const doubl
     if (n < 1 || !G || !out || nG < 3) return fail(c, MSGW_ERR_ARG, "bad projection arguments");
     const double *h[11] = {dens, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, dll, dmm, fray};
     for (const double *p : h) if (!p) return fail(c, MSGW_ERR_ARG, "NULL array");
+    if (std::isnan(bvf) && !(c->nz && c->bvfcol && c->have_column))
+        return fail(c, MSGW_ERR_ARG, "bvf = NaN asks for the context's N(z) column, but none is set "
+                    "(msgw_set_bvf_column, msgw_set_column)");
     HIPCHK(c, hipSetDevice(c->device));
     const int tile = Real<double>::TILE;                       // caller arrays are float64 whatever the context holds
     const size_t padded = (((size_t)n + tile - 1) / tile) * tile;
@@ -1633,6 +1681,10 @@ int msgw_project_arrays(msgw_ctx *c, int64_t n, int var, double bvf, const doubl
         a.n = n; a.nG = nG; a.var = (var == 3) ? 1 : (var == 4 ? 0 : var); a.boundary = var >= 3;
         a.bvf2 = std::pow(bvf, 2.0); a.f_uni = 0.0; a.dz = G[1] - G[0];
         a.cdz = 1.0 / a.dz; a.mk_ok = markstein_ok(a.dz);
+        if (std::isnan(bvf)) {                                 // N from the context's column, at .5 * (rr_low + rr_up)
+            a.bvfcol = c->bvfcol; a.grids = c->grids; a.nc = c->ng - 1;
+            a.gs0 = c->gs0; a.gs_last = c->gs_last; a.inv_dzs = 1.0 / c->dzs;
+        }
         a.e = ProjExplicit{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10]};
         const int np = (var == 0 || var == 4) ? 2 : 1;
         rc = run_projection(c, a, project_arrays_kernel(np), tile, np, G, nG, out);
@@ -1670,6 +1722,7 @@ int msgw_saturation(msgw_ctx *c, int64_t n, double dt, int direct, const double 
         a.kk = b + 5 * n; a.ll = b + 6 * n; a.mm = b + 7 * n; a.mm_st = b + 8 * n;
         a.dkk = b + 9 * n; a.dll = b + 10 * n; a.area = b + 11 * n;
         a.grids = c->grids; a.rhobar = c->rhobar; a.slrho = c->slrho;
+        a.bvfcol = c->nz ? c->bvfcol : nullptr;
         a.out = buf + (size_t)n * 12;
         rc = launch_struct(c, saturation_kernel(), (unsigned)((n + BLOCK - 1) / BLOCK), BLOCK, 0, a);
         if (rc == MSGW_OK && hipMemcpyAsync(out, a.out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
@@ -1747,8 +1800,11 @@ int msgw_snapshot_create(msgw_ctx *c, msgw_snapshot **out)
     }
     s->n = c->n;
     for (int k = 0; k < MSGW_SLOT_COUNT; ++k)
-        if (s->len[k])
-            HIPCHK(c, hipMemcpyAsync(static_cast<char *>(s->buf) + s->off[k], src[k], s->len[k], hipMemcpyDeviceToDevice, c->stream));
+        if (s->len[k] &&
+            hipMemcpyAsync(static_cast<char *>(s->buf) + s->off[k], src[k], s->len[k], hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+            (void)msgw_snapshot_destroy(c, s);                 // back to the pool (or freed): nothing leaks on the error path
+            return fail(c, MSGW_ERR_HIP, "device copy of a snapshot failed");
+        }
     *out = s;
     return MSGW_OK;
 }

@@ -329,6 +329,17 @@ __device__ __forceinline__ T interp_eval(T x, const Bracket<T> &b, T fpj, T slj)
     return b.flat ? fpj : lin;
 }
 
+// np.interp(x, grids, f) on arrays in GLOBAL memory (the standalone entry points; the stage kernels stage their tables
+// in LDS): numpy's own slope expression (f[j+1]-f[j])/(x[j+1]-x[j]), end values beyond the table
+__device__ __forceinline__ double interp_global(double x, const double *xp, const double *fp, int n, double x_first,
+                                                double x_last, double inv_dx)
+{
+    const Bracket<double> b = interp_locate(x, xp, n, x_first, x_last, x_first, inv_dx);
+    const int j0 = min(b.j, n - 2);                          // (b.j == n-1: flat, the slope is not used)
+    const double sl = (fp[j0 + 1] - fp[j0]) / (xp[j0 + 1] - xp[j0]);
+    return interp_eval(x, b, fp[b.j], sl);
+}
+
 // numpy `.astype(int)` on x86-64 (lib/libprop.py:124-125) kept in the floating-point
 // domain: truncation toward zero; NaN/inf/out-of-range behave as INT64_MIN.
 template <typename T>
@@ -851,27 +862,27 @@ __device__ __forceinline__ void deposit_pass(const StageArgsT<T> a, const StageL
 }
 
 // stage the static tables of the column (float64 in global memory) into the LDS views
-template <typename T>
+template <typename T, int STRIDE = BLOCK>
 __device__ __forceinline__ void stage_shear_table(const StageCarve<T> &C, const ColPtrs c, int ni, int tid)
 {
-    for (int i = tid; i < ni; i += BLOCK) {
+    for (int i = tid; i < ni; i += STRIDE) {
         const bool in = i < ni - 1;                      // the last point has no slope (never used)
         C.sh[i] = Real<T>::quad((T)c.dudz[i], in ? (T)c.slu[i] : T(0), (T)c.dvdz[i], in ? (T)c.slv[i] : T(0));
     }
 }
-template <typename T>
+template <typename T, int STRIDE = BLOCK>
 __device__ __forceinline__ void stage_xg(const StageCarve<T> &C, const ColPtrs c, int ni, int tid)
 {
-    for (int i = tid; i < ni; i += BLOCK) {
+    for (int i = tid; i < ni; i += STRIDE) {
         const double x = c.xg[i];
         C.xg[i] = (T)x;
         if constexpr (!std::is_same<T, double>::value) C.xgd[i] = x;
     }
 }
-template <typename T>
+template <typename T, int STRIDE = BLOCK>
 __device__ __forceinline__ void stage_rho(const StageCarve<T> &C, const ColPtrs c, int nc, int tid, bool rho)
 {
-    for (int i = tid; i < nc; i += BLOCK) {
+    for (int i = tid; i < nc; i += STRIDE) {
         C.gs[i] = (T)c.grids[i];
         if (rho) C.rho2[i] = Real<T>::pair((T)c.rhobar[i], (i < nc - 1) ? (T)c.slrho[i] : T(0));
     }
@@ -991,12 +1002,20 @@ __global__ void __launch_bounds__(BLOCK) k_deposit_only(const StageArgsT<T> a)
 // dependency, so the three stages run back to back per ray, and ALL the steps of
 // a call run in one launch: rr, mm (dens) touch HBM once per call, not per step
 // (same arithmetic in the same order: bit-identical to one launch per step).
-template <typename T, bool SAT, bool FVEC, bool DIRECT>
-__global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgsT<T> a)
+// NARROW = false: 256-thread workgroups, 2 rays per lane (16-B / 8-B accesses), tiles of 512 rays.
+// NARROW = true : ONE wavefront per workgroup, ONE ray per lane, tiles of 64 rays -- the geometry of small ray counts
+// (BASELINE config 2: 1e5 rays).  The kernel is bound by the instruction issue of dependent float64 chains (three IEEE
+// divisions and a square root per ray-stage, ~130 instructions each in sequence), not by memory: with 2 rays per lane
+// 1e5 rays are 784 wavefronts -- one per SIMD on 784 of the chip's 1024 SIMDs, each issuing two rays' chains alone
+// (profiles/r02_config2_summary.md: VALU 41 % busy).  With one ray per lane they are 1563 wavefronts on ALL SIMDs,
+// half the chain per wavefront, and a SIMD that hosts two of them interleaves their issue.
+template <typename T, bool SAT, bool FVEC, bool DIRECT, bool NARROW = false>
+__global__ void __launch_bounds__(NARROW ? 64 : BLOCK) k_ray_step_fixed(const StageArgsT<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int RPT = Real<T>::RPT;
-    constexpr int TILE = Real<T>::TILE;
+    constexpr int RPT = NARROW ? 1 : Real<T>::RPT;
+    constexpr int BLK = NARROW ? 64 : BLOCK;
+    constexpr int TILE = BLK * RPT;
     typedef typename Real<T>::quad_t quad_t;
     typedef typename Real<T>::pair_t pair_t;
     const int ng = a.ng, ni = ng - 2, nc = ng - 1;
@@ -1006,9 +1025,9 @@ __global__ void __launch_bounds__(BLOCK) k_ray_step_fixed(const StageArgsT<T> a)
     const pair_t *s_rho2 = C.rho2;
     const T *s_xg = C.xg, *s_gs = C.gs;
     const int tid = threadIdx.x;
-    stage_xg(C, a.c, ni, tid);
-    stage_shear_table(C, a.c, ni, tid);
-    if (NEED_RHO) stage_rho(C, a.c, nc, tid, true);
+    stage_xg<T, BLK>(C, a.c, ni, tid);
+    stage_shear_table<T, BLK>(C, a.c, ni, tid);
+    if (NEED_RHO) stage_rho<T, BLK>(C, a.c, nc, tid, true);
     __syncthreads();
 
     const long long start = (long long)blockIdx.x * a.rays_per_block;
@@ -1123,6 +1142,10 @@ struct ProjArgsT {
     const double *G;
     double *partial;      // [blocks][NP][nG-1]
     int *ranges;
+    // EXTENSION: N as a column on `grids` (float64 contexts; nullptr: the scalar in bvf2), taken at the ray centre
+    const double *bvfcol, *grids;
+    int nc;
+    double gs0, gs_last, inv_dzs;
 };
 typedef ProjArgsT<double> ProjArgs;
 
@@ -1153,7 +1176,9 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
         bool valid[RPT];
 #pragma unroll
         for (int r = 0; r < RPT; ++r) valid[r] = e0 + r < a.n;
-        T kk[RPT], ll[RPT], dens[RPT], vol[RPT], ff[RPT], lo[RPT], up[RPT], mmid[RPT];
+        T kk[RPT], ll[RPT], dens[RPT], vol[RPT], ff[RPT], lo[RPT], up[RPT], mmid[RPT], zctr[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) zctr[r] = T(0);
         if constexpr (EXPL) {
             T mlo[RPT], mup[RPT], dkk[RPT], dll[RPT], dmm[RPT];
             loadv(a.e.dens, i0, dens);
@@ -1187,11 +1212,15 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
             for (int r = 0; r < RPT; ++r) {
                 lo[r] = rr[r] - T(.5) * drr[r];                       // :655 / raytracer.py:200-201
                 up[r] = rr[r] + T(.5) * drr[r];
+                zctr[r] = rr[r];
                 mmid[r] = T(.5) * ((mm[r] - T(.5) * dmm[r]) + (mm[r] + T(.5) * dmm[r]));   // :141, :656
             }
         }
         T pay[NP][RPT];
         int nlo[RPT], nup[RPT];
+        T zlo[RPT], zup[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) { zlo[r] = lo[r]; zup[r] = up[r]; }
 #pragma unroll
         for (int r = 0; r < RPT; ++r) {
             deposit_indices<NP>(lo[r], up[r], valid[r], a.dz, a.cdz, a.mk_ok, nG - 2, nlo[r], nup[r]);
@@ -1201,7 +1230,15 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
             }
             const T f = (FVEC || EXPL) ? ff[r] : a.f_uni;
             T kh2, m2, vk2, om, cgr;
-            dispersion(kk[r], ll[r], mmid[r], f * f, a.bvf2, kh2, m2, vk2, om, cgr);
+            T bvf2 = a.bvf2;
+            if constexpr (std::is_same<T, double>::value) {
+                if (a.bvfcol) {                                       // (kernel-uniform) N at the ray centre
+                    const double zc = EXPL ? .5 * (zlo[r] + zup[r]) : zctr[r];
+                    const double N = interp_global(zc, a.grids, a.bvfcol, a.nc, a.gs0, a.gs_last, a.inv_dzs);
+                    bvf2 = N * N;
+                }
+            }
+            dispersion(kk[r], ll[r], mmid[r], f * f, bvf2, kh2, m2, vk2, om, cgr);
             if (NP == 2) { pay[0][r] = cgr * kk[r] * dens[r]; pay[NP - 1][r] = cgr * ll[r] * dens[r]; }   // :148-149
             else pay[0][r] = (a.var == 1) ? cgr * dens[r] : dens[r];                     // :167, :184
         }
@@ -1219,6 +1256,7 @@ struct SatArgs {
     double dt, bvf2, f0sq, sat_c, gs0, gs_last, inv_dzs;
     const double *dens, *rr, *rr_st, *drr, *drr_st, *kk, *ll, *mm, *mm_st, *dkk, *dll, *area;
     const double *grids, *rhobar, *slrho;
+    const double *bvfcol;   // EXTENSION: N on grids (nullptr: the scalar in bvf2); N at rr_center and at rr_final
     double *out;
 };
 

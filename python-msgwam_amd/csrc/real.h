@@ -74,6 +74,16 @@ __device__ __forceinline__ void storev(float *p, unsigned int off, const float (
     *reinterpret_cast<float2 *>(reinterpret_cast<char *>(p) + off) = make_float2(v[0], v[1]);
 }
 
+// one ray per lane (the fixed-background kernel at small ray counts, see k_ray_step_fixed): 8-B / 4-B accesses
+template <typename T> __device__ __forceinline__ void loadv(const T *p, unsigned int off, T (&out)[1])
+{
+    out[0] = *reinterpret_cast<const T *>(reinterpret_cast<const char *>(p) + off);
+}
+template <typename T> __device__ __forceinline__ void storev(T *p, unsigned int off, const T (&v)[1])
+{
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(p) + off) = v[0];
+}
+
 // max / min of two values in ONE instruction (v_max / v_min; a `(a > b) ? a : b` costs a compare, its hazard slot and two
 // v_cndmask per float64).  Used where the operands cannot be NaN (the overlap of a contributing ray volume with a grid
 // cell, lib/libprop.py:157-158: rays with a NaN bound are out of domain and never reach the level loop); for such

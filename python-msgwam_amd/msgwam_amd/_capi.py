@@ -42,7 +42,9 @@ class Counters(C.Structure):
                 ("graph_steps", C.c_int32), ("nranks", C.c_int32), ("persist_steps", C.c_int32),
                 ("exchange", C.c_int32),
                 ("persist_resident_tiles", C.c_int32), ("elem_bytes", C.c_int32),
-                ("transport", C.c_int32), ("tenants", C.c_int32)]
+                ("transport", C.c_int32), ("tenants", C.c_int32),
+                ("launch_grid", C.c_int32), ("launch_ray_workgroups", C.c_int32), ("launch_reducers", C.c_int32),
+                ("fixed_narrow", C.c_int32), ("algorithmic_bytes_total", C.c_double)]
 
 
 class MsgwError(RuntimeError):
@@ -89,7 +91,7 @@ def load_library():
     lib.msgw_set_bvf_column.argtypes = [C.c_void_p, _dp]
     lib.msgw_download_extents.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp, _dp]
     lib.msgw_snapshot_destroy.argtypes = [C.c_void_p, C.c_void_p]
-    if lib.msgw_abi_version() != 2:
+    if lib.msgw_abi_version() != 3:
         raise MsgwError("libmsgwam_hip.so has an unexpected ABI version")
     _lib = lib
     return lib

@@ -13,9 +13,12 @@ setters; `omega`; and the hot-path entry points `RK3`, `rhs_default`,
 fallback for those four: without the HIP library or a GPU they raise.
 
 Scope and deliberate differences (also in DESIGN.md):
-  * Only a scalar `bvf` is implemented.  Both `HPROP_GLOBAL` branches run on the GPU: False (the driver's,
-    raytracer.py:38) through the tuned kernels, True (lam, phi, kk, ll evolve as well) through a plain kernel of
-    its own.
+  * `model_config['bvf']` is the reference's scalar or (EXTENSION) an array on `grids`; the array
+    form works with `HPROP_GLOBAL = False` only.  Both `HPROP_GLOBAL` branches run on the GPU: False (the driver's,
+    raytracer.py:38) through the tuned kernels, True (lam, phi, kk, ll evolve as well) through a kernel of its own.
+  * The reference's other building blocks (`gradients`, `cg_*`, `dk_dt` ... `dv_dt`, `velocities_tanh`) are NOT
+    mirrored: they are internals of its `rhs_default` (no caller in `raytracer.py`), and a numpy copy of them here
+    would be a CPU path beside the GPU one.
   * `model_config['rhs']` is honoured as in the reference (lib/libprop.py:691).  With the built-ins `rhs_default` /
     `rhs_fixed_background` a whole `RK3` step is one GPU call; any other callable (e.g. a hook around
     `lprop.rhs_default`) is driven by the reference's six RK lines on the host, its `rhs_default` calls on the GPU.
@@ -114,118 +117,24 @@ def omega(kk, ll, mm, phi):
 
 
 # ----------------------------------------------------------------------------
-# The building blocks of the reference's rhs_default as host-side numpy helpers (same names, argument
-# orders and module globals as lib/libprop.py).  They are here for scripts that call them directly, e.g.
-# to plot group velocities; the GPU path has its own implementation and never calls them.
-# ----------------------------------------------------------------------------
-def _horizontal_norm(rr):
-    return RAD_EARTH + rr
-
-
-def gradients(lam_ray, phi_ray, rr_ray, uu, vv):
-    """lib/libprop.py:328-366: winds and wind gradients at the rays, shape (4, 3) + rays.shape:
-    [0] = (u, v, w), [1] = grad u, [2] = grad v, [3] = grad w in (lam, phi, r).  Only the vertical shear
-    is non-zero in the 1-D column."""
-    dz = np.diff(grid[:2])[0]
-    out = np.zeros((4, 3) + np.shape(lam_ray))
-    out[0, 0] = np.interp(rr_ray, grids, uu)
-    out[0, 1] = np.interp(rr_ray, grids, vv)
-    out[1, 2] = np.interp(rr_ray, grid[1:-1], (uu[1:] - uu[:-1]) / dz)
-    out[2, 2] = np.interp(rr_ray, grid[1:-1], (vv[1:] - vv[:-1]) / dz)
-    return out
-
-
-def cg_rr(kk, ll, mm, lam, phi, rr):
-    """lib/libprop.py:434-448: vertical group velocity."""
-    ff = 2 * ROT_EARTH * np.sin(phi)
-    om = omega(kk, ll, mm, phi)
-    return - mm * (om ** 2 - ff ** 2) / om / (kk ** 2 + ll ** 2 + mm ** 2)
-
-
-def _cg_horizontal(kh, kk, ll, mm, phi, wind_ray):
-    if not HPROP_GLOBAL:                                   # :406, :430
-        return np.zeros(np.shape(kk))
-    bvf = model_config['bvf']
-    om = omega(kk, ll, mm, phi)
-    return kh / om / (kk ** 2 + ll ** 2 + mm ** 2) * (bvf ** 2 - om ** 2) + wind_ray
-
-
-def cg_lambda(kk, ll, mm, lam, phi, rr, uu, vv):
-    """lib/libprop.py:385-407: zonal group velocity (zero with HPROP_GLOBAL off)."""
-    return _cg_horizontal(kk, kk, ll, mm, phi, np.interp(rr, grids, uu))
-
-
-def cg_phi(kk, ll, mm, lam, phi, rr, uu, vv):
-    """lib/libprop.py:409-431: meridional group velocity (zero with HPROP_GLOBAL off)."""
-    return _cg_horizontal(ll, kk, ll, mm, phi, np.interp(rr, grids, vv))
-
-
-def dk_dt(kk, ll, mm, lam, phi, rr, uu, vv):
-    """lib/libprop.py:451-471: tendency of the zonal wavenumber (zero with HPROP_GLOBAL off)."""
-    if not HPROP_GLOBAL:
-        return np.zeros(np.shape(kk))
-    vel = gradients(lam, phi, rr, uu, vv)
-    gradient = (kk * vel[1, 0] + ll * vel[2, 0]) / _horizontal_norm(rr) / np.cos(phi)
-    return kk / _horizontal_norm(rr) * (np.tan(phi) * cg_phi(kk, ll, mm, lam, phi, rr, uu, vv)
-                                        - cg_rr(kk, ll, mm, lam, phi, rr)) - gradient
-
-
-def dl_dt(kk, ll, mm, lam, phi, rr, uu, vv):
-    """lib/libprop.py:474-499: tendency of the meridional wavenumber (zero with HPROP_GLOBAL off)."""
-    if not HPROP_GLOBAL:
-        return np.zeros(np.shape(kk))
-    vel = gradients(lam, phi, rr, uu, vv)
-    gradient = (kk * vel[1, 1] + ll * vel[2, 1]) / _horizontal_norm(rr)
-    df2_dphi = 8 * ROT_EARTH ** 2 * np.sin(phi) * np.cos(phi) * 1
-    return - (ll * cg_rr(kk, ll, mm, lam, phi, rr)
-              + kk * np.tan(phi) * cg_lambda(kk, ll, mm, lam, phi, rr, uu, vv)
-              + mm ** 2 / 2 / omega(kk, ll, mm, phi) / (kk ** 2 + ll ** 2 + mm ** 2) * df2_dphi) \
-        / _horizontal_norm(rr) - gradient
-
-
-def dm_dt(kk, ll, mm, lam, phi, rr, uu, vv):
-    """lib/libprop.py:502-520: tendency of the vertical wavenumber."""
-    vel = gradients(lam, phi, rr, uu, vv)
-    gradient = kk * vel[1, 2] + ll * vel[2, 2]
-    return (kk * cg_lambda(kk, ll, mm, lam, phi, rr, uu, vv)
-            + ll * cg_phi(kk, ll, mm, lam, phi, rr, uu, vv)) / _horizontal_norm(rr) - gradient
-
-
-def du_dt(vv, pm_flux_gradient):
-    """lib/libprop.py:523-539: zonal mean-flow tendency."""
-    ff = 2 * ROT_EARTH * np.sin(model_config['phi0'])
-    return ff * vv - rhobar ** -1 * (pressure_gradient[0] + pm_flux_gradient)
-
-
-def dv_dt(uu, pm_flux_gradient):
-    """lib/libprop.py:542-558: meridional mean-flow tendency."""
-    ff = 2 * ROT_EARTH * np.sin(model_config['phi0'])
-    return -ff * uu - rhobar ** -1 * (pressure_gradient[1] + pm_flux_gradient)
-
-
-def velocities_tanh(lam, phi, rr):
-    """lib/libprop.py:222-246: jet, Gaussian in latitude and tanh in height; (4, 3) + lam.shape with the
-    wind written into the whole first row, as there."""
-    c = model_config
-    shape = np.exp(-(phi - c['phi0']) ** 2 / 2 / c['sig_phi'] ** 2) * (np.tanh((rr - c['rr0']) / c['sig_rr']) + 1) * 0.5
-    out = np.zeros((4, 3) + np.shape(lam))
-    out[0] = c['u0'] * shape
-    return out
-
-# ----------------------------------------------------------------------------
 # device backend
 # ----------------------------------------------------------------------------
+def _digest_stdlib(a):
+    """Position-sensitive content digest without third-party modules (a swap of two rays, an in-place sort or any
+    other reordering changes it): blake2b over the raw bytes."""
+    import hashlib
+    a = np.ascontiguousarray(a)
+    return (a.shape, a.dtype.str, hashlib.blake2b(memoryview(a).cast("B"), digest_size=16).digest())
+
+
 try:                                                     # content digests of host arrays (residency checks)
     import xxhash as _xxhash
 
     def _digest(a):
         a = np.ascontiguousarray(a)
         return (a.shape, a.dtype.str, _xxhash.xxh3_64_intdigest(memoryview(a).cast("B")))
-except ImportError:                                      # numpy only: wrap-around sum and xor of the 64-bit words
-    def _digest(a):
-        a = np.ascontiguousarray(a)
-        w = a.view(np.uint64) if a.dtype.itemsize == 8 and a.size else np.frombuffer(a.tobytes(), dtype=np.uint8)
-        return (a.shape, a.dtype.str, int(np.add.reduce(w, dtype=np.uint64)), int(np.bitwise_xor.reduce(w)) if w.size else 0)
+except ImportError:                                      # xxhash is optional: the standard library's blake2b instead
+    _digest = _digest_stdlib
 
 
 def _sampled(a):
@@ -806,7 +715,16 @@ def wave_projection(dens, lam, phi, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk, d
     n = len(dens)
     ng = len(globals()['grid']) if globals()['grid'] is not None else len(grid)
     p = _backend.context(ng, n)
-    return p.project_arrays(var, model_config['bvf'], dens, phi, rr_low, rr_up, kk, ll, mm_low, mm_up,
+    bvf = model_config['bvf']
+    if np.ndim(bvf) != 0:                                        # EXTENSION: N(z) column, N at .5 * (rr_low + rr_up)
+        _check_scope()
+        if _backend.col is None:                                 # the caller never ran RK3: any wind column will do
+            z = np.zeros(len(grids))
+            _sync_config_and_column(p, z, z, force_uv=True)
+        else:
+            _sync_config_only(p)
+        bvf = np.nan                                             # msgw_project_arrays: "the context's column"
+    return p.project_arrays(var, bvf, dens, phi, rr_low, rr_up, kk, ll, mm_low, mm_up,
                             dkk, dll, dmm, grid)
 
 

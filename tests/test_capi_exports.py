@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/msgwam_hip.h but not exported"
     assert sorted(_capi.EXPORTS) == names
-    assert lib.msgw_abi_version() == 2          # MSGW_ABI_VERSION of include/msgwam_hip.h
+    assert lib.msgw_abi_version() == 3          # MSGW_ABI_VERSION of include/msgwam_hip.h
 
 
 def test_binding_loads_and_fails_loudly_without_gpu():

@@ -207,3 +207,60 @@ def test_bvf_column_through_the_module_surface_and_scope():
     with pytest.raises(_capi.MsgwError, match="float64 only"):
         p32.set_bvf_column(col)
     p32.close()
+
+
+def test_standalone_saturation_and_projection_use_the_column():
+    """`lprop.saturation` (the driver's post-step call, raytracer.py:182-188) and `lprop.wave_projection`
+    with `model_config['bvf']` as a column must follow the extension's definition (N at rr_center for omega, at the
+    projected height for the cap; N at the ray centre in the projections) -- not a scalar mean of the column."""
+    import msgwam_amd.libprop as lprop
+    s, st = _random_case(5003, 61, True, "uniform", False)
+    col = _column(s.grids, 7)
+    s.bvf = col
+    dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = st
+    rng = np.random.default_rng(8)
+    rr_st = rng.normal(0, 20.0, len(rr))
+    drr_st = rng.normal(0, 1e-3, len(rr))
+    mm_st = mm * rng.normal(0, 1e-4, len(rr))
+    big = dens * 10.0 ** rng.uniform(0, 14, len(rr))                 # so that a good share of the rays saturates
+    lprop.HPROP_GLOBAL = False
+    lprop.set_model_setup(bvf=col, rhs=lprop.rhs_default, phi0=s.phi0, kappa=s.kappa, saturate_online=False)
+    lprop.grid, lprop.grids, lprop.rhobar, lprop.pressure_gradient = s.grid, s.grids, s.rhobar, s.pressure_gradient
+    lprop.set_statics(dkk=s.dkk, dll=s.dll, rr_mm_area=s.rr_mm_area)
+    try:
+        for direct in (True, False):
+            want = orc.saturation(s, 60.0, big, rr, rr_st, drr, drr_st, kk, ll, mm, mm_st, direct=direct)
+            got = lprop.saturation(60.0, big, rr, rr_st, drr, drr_st, kk, ll, mm, mm_st, direct=direct)
+            hit = want != (big if direct else 0.0)
+            assert 0.05 * len(rr) < np.count_nonzero(hit) < 0.95 * len(rr)
+            assert relerr(got, want) <= 1e-12, direct
+            # and it is NOT what a scalar mean of the column gives
+            s_mean = orc.Setup(s.grid, bvf=float(np.mean(col)), phi0=s.phi0, kappa=s.kappa, saturate_online=True,
+                               dkk=s.dkk, dll=s.dll, rr_mm_area=s.rr_mm_area)
+            wrong = orc.saturation(s_mean, 60.0, big, rr, rr_st, drr, drr_st, kk, ll, mm, mm_st, direct=direct)
+            assert relerr(wrong, want) > 1e-3
+        lo, up = rr - .5 * drr, rr + .5 * drr
+        for G in (s.grid, s.grids):
+            for var in (0, 1, 2, 3, 4):
+                want = orc.wave_projection(dens, lo, up, kk, ll, mm - .5 * dmm, mm + .5 * dmm, phi, s.dkk, s.dll, dmm, G,
+                                           orc.bvf_at(s, .5 * (lo + up)), var=var)
+                got = lprop.wave_projection(dens, lam, phi, lo, up, kk, ll, mm - .5 * dmm, mm + .5 * dmm, s.dkk, s.dll,
+                                            dmm, G, var=var)
+                assert got.shape == want.shape
+                assert prof_err(np.atleast_2d(got), np.atleast_2d(want)) <= 1e-12, (var, len(G))
+    finally:
+        lprop.set_model_setup(bvf=0.01, saturate_online=True)
+        lprop.release_device()
+    # the resident projection (msgw_project): N at the resident ray centre rr
+    p = make_prop_nz(s, st, col)
+    for var in (0, 1, 2):
+        want = orc.wave_projection(dens, lo, up, kk, ll, mm - .5 * dmm, mm + .5 * dmm, phi, s.dkk, s.dll, dmm, s.grids,
+                                   orc.bvf_at(s, rr), var=var)
+        assert prof_err(np.atleast_2d(p.project(var, s.grids)), np.atleast_2d(want)) <= 1e-12, var
+    p.close()
+    # a scalar context asked for "the context's column" says so
+    q = _capi.Propagator(len(s.grid), 16)
+    with pytest.raises(_capi.MsgwError, match="N\\(z\\) column"):
+        q.project_arrays(0, np.nan, dens[:8], phi[:8], lo[:8], up[:8], kk[:8], ll[:8], mm[:8], mm[:8], s.dkk[:8] if np.ndim(s.dkk) else s.dkk,
+                         s.dll[:8] if np.ndim(s.dll) else s.dll, dmm[:8], s.grids)
+    q.close()

@@ -268,6 +268,9 @@ def test_full_size_config3_properties_and_subsample():
     want = COracle(s).step(120.0, 2, st)
     p = make_prop(s, st)
     p.step(120.0, 2)
+    c = p.counters()                                           # the flavour bench.py times is the one held to the oracle
+    assert c["persist_steps"] == 2 and c["persist_resident_tiles"] == 4 and c["launch_reducers"] > 0
+    assert c["launch_grid"] == c["launch_ray_workgroups"] + c["launch_reducers"] + 1
     got = gpu_state(p, st)
     assert np.array_equal(got[0], st[0])                       # dens constant without saturation
     check_state(got, want, 1e-10, 1e-11, "config3")
@@ -291,7 +294,9 @@ def test_full_size_config2_fixed_background_1000_steps():
     want = COracle(s, fixed_background=True).step(120.0, 1000, st)
     p = make_prop(s, st)
     p.step(120.0, 1000, _capi.FIXED_BACKGROUND)
-    assert p.counters()["persist_steps"] == 1000
+    c = p.counters()
+    assert c["persist_steps"] == 1000
+    assert c["fixed_narrow"] == 1 and c["launch_grid"] == (n + 63) // 64      # one ray per lane: 1563 wavefronts
     one = gpu_state(p, st)
     p.close()
     p = make_prop(s, st)
@@ -304,6 +309,32 @@ def test_full_size_config2_fixed_background_1000_steps():
     for i, k in ((0, "dens"), (3, "rr"), (7, "mm")):
         assert relerr(one[i], want[i]) <= 1e-10, (k, relerr(one[i], want[i]))
     assert np.array_equal(one[9], st[9]) and np.array_equal(one[10], st[10])
+
+
+def test_fixed_background_forms_agree_bitwise(monkeypatch):
+    """The two geometries of the fused fixed-background kernel -- one ray per lane in one-wavefront workgroups (small
+    ray counts, BASELINE config 2) and two rays per lane in 256-thread workgroups -- run the same per-ray arithmetic:
+    bit-identical results, at sizes on either side of every tile boundary, with and without saturation / relaunch."""
+    for n, seed, sat, flags in ((1, 1, False, 0), (63, 2, True, 0), (64, 3, False, _capi.DIRECT_SAT), (65, 4, False, _capi.RELAUNCH),
+                                (513, 5, True, _capi.RELAUNCH), (100_001, 6, False, 0)):
+        s, st = _random_case(n, 300 + seed, sat, "vector" if seed % 2 else "uniform", False)
+        res = []
+        for narrow in ("1", "0"):
+            monkeypatch.setenv("MSGW_FIXED_NARROW", narrow)
+            p = make_prop(s, st)
+            p.step(60.0, 7, _capi.FIXED_BACKGROUND | flags)
+            assert p.counters()["fixed_narrow"] == int(narrow)
+            res.append(gpu_state(p, st))
+            p.close()
+        for k, a, b in zip(STATE_KEYS, *res):
+            assert np.array_equal(a, b, equal_nan=True), (n, k)
+    monkeypatch.delenv("MSGW_FIXED_NARROW")
+    # default choice by size
+    s, st = _random_case(500_000, 9, False)
+    p = make_prop(s, st)
+    p.step(60.0, 1, _capi.FIXED_BACKGROUND)
+    assert p.counters()["fixed_narrow"] == 0
+    p.close()
 
 
 def _tall_case(ngrid, n, seed=77):

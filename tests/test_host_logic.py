@@ -60,52 +60,6 @@ def test_spectrum_is_deterministic_and_shardable():
     assert [shard_bounds(7, 3, r) for r in range(3)] == [(0, 2), (2, 4), (4, 7)]
 
 
-def test_rhs_building_blocks_match_the_reference():
-    """cg_rr, cg_lambda, cg_phi, dk_dt, dl_dt, dm_dt, gradients, du_dt, dv_dt (host-side numpy helpers of the
-    module surface) against tendencies produced by the real reference (goldens g6 with HPROP on, g1 with it
-    off): bit for bit."""
-    import numpy as np
-    import msgwam_amd.libprop as lprop
-    from helpers import load, state_from
-
-    def configure(d, hprop):
-        lprop.HPROP_GLOBAL = hprop
-        lprop.set_model_setup(bvf=float(d["bvf"]), phi0=float(d["phi0"]), kappa=float(d["kappa"]),
-                              saturate_online=False, boussinesq=False, hh=8500, rhobar0=1.2)
-        g = d["grid"]
-        lprop.grid, lprop.grids = g, .5 * (g[:-1] + g[1:])
-        lprop.set_hydrostatics()
-        lprop.pressure_gradient = d["pg"].copy()
-
-    try:
-        d = load("g6_hprop_rhs_sat0")
-        configure(d, True)
-        dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = state_from(d, "in")
-        R = lprop.RAD_EARTH + rr
-        assert np.array_equal(lprop.cg_rr(kk, ll, mm, lam, phi, rr), d["out_rr"])
-        assert np.array_equal(lprop.cg_lambda(kk, ll, mm, lam, phi, rr, uu, vv) / R / np.cos(phi), d["out_lam"])
-        assert np.array_equal(lprop.cg_phi(kk, ll, mm, lam, phi, rr, uu, vv) / R, d["out_phi"])
-        assert np.array_equal(lprop.dk_dt(kk, ll, mm, lam, phi, rr, uu, vv), d["out_kk"])
-        assert np.array_equal(lprop.dl_dt(kk, ll, mm, lam, phi, rr, uu, vv), d["out_ll"])
-        assert np.array_equal(lprop.dm_dt(kk, ll, mm, lam, phi, rr, uu, vv), d["out_mm"])
-        g = lprop.gradients(lam, phi, rr, uu, vv)
-        assert g.shape == (4, 3, len(rr)) and np.array_equal(g[0, 0], np.interp(rr, lprop.grids, uu))
-        d = load("g1_rhs_f45_sat0")
-        configure(d, False)
-        dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = state_from(d, "in")
-        assert not np.any(lprop.cg_lambda(kk, ll, mm, lam, phi, rr, uu, vv)) and not np.any(lprop.dk_dt(kk, ll, mm, lam, phi, rr, uu, vv))
-        assert np.array_equal(lprop.dm_dt(kk, ll, mm, lam, phi, rr, uu, vv), d["out_mm"])
-        F = np.zeros((2, len(d["grid"])))
-        F[:, 1:-1] = d["pm_flux_inner"]
-        F[:, 0], F[:, -1] = F[:, 1], F[:, -2]
-        dF = (F[:, 1:] - F[:, :-1]) / np.diff(d["grid"][:2])[0]
-        assert np.array_equal(lprop.du_dt(vv, dF[0]), d["out_uu"]) and np.array_equal(lprop.dv_dt(uu, dF[1]), d["out_vv"])
-        v = lprop.velocities_tanh(np.zeros(5), np.full(5, float(d["phi0"])), np.linspace(0, 8e4, 5))
-        assert v.shape == (4, 3, 5) and np.array_equal(v[0, 0], v[0, 2])
-    finally:
-        lprop.HPROP_GLOBAL = False
-
-
 def test_rk3_drives_a_foreign_rhs_hook_with_the_reference_rk_lines():
     """model_config['rhs'] may be any callable (lib/libprop.py:691).  A hook that never touches the GPU: linear
     tendencies, for which the Williamson scheme (lib/libprop.py:693-698) has a closed form."""
@@ -199,3 +153,22 @@ def test_residency_fingerprints_see_in_place_edits():
     lprop.set_residency("off")
     assert lprop._slot_key(a) is None and not lprop._slot_resident(a, key)
     lprop.set_residency("safe")
+
+
+def test_digest_without_xxhash_is_position_sensitive(monkeypatch):
+    """the fallback digest (xxhash not installed) must see a reordering -- a swap of two rays, an
+    in-place sort -- not only a change of the multiset of values."""
+    import msgwam_amd.libprop as lprop
+    monkeypatch.setattr(lprop, "_digest", lprop._digest_stdlib)      # what the ImportError branch installs
+    lprop.set_residency("safe")
+    a = np.random.default_rng(5).normal(size=10_000)
+    key = lprop._slot_key(a)
+    assert lprop._slot_resident(a, key)
+    a[[17, 4711]] = a[[4711, 17]]                                    # swap: same sum, same xor
+    assert not lprop._slot_resident(a, key)
+    a[[17, 4711]] = a[[4711, 17]]
+    assert lprop._slot_resident(a, key)
+    a.sort()                                                         # in-place reordering
+    assert not lprop._slot_resident(a, key)
+    e = np.zeros(0)
+    assert lprop._slot_resident(e, lprop._slot_key(e))               # empty arrays digest too

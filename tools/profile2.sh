@@ -10,6 +10,7 @@ mkdir -p "$OUT"
 SCRIPT=$ROOT/$1; shift
 cd /tmp && export TMPDIR=/tmp
 echo "python3 $SCRIPT $*" > "$OUT/command.txt"
+(cd "$ROOT" && python3 -c "import bench; print(bench.kernel_src_digest())") > "$OUT/src_digest.txt" 2>/dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$SCRIPT" "$@" > "$OUT/trace.log" 2>&1 || echo "trace pass failed"
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
