@@ -168,7 +168,7 @@ def copy_ceiling(torch, nbytes=1 << 30, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=0, help="timed RK3 steps (default 200; config2: 1000, SURVEY 8d \">= 1000 steps timed\")")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=0, help="timed repeats of K steps (0 = until the timed region is >= 50 ms, at least 5)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + sorted(ALIASES), default=None,
@@ -208,6 +208,8 @@ def main():
         raise SystemExit("--total-rays and --rays-per-gpu exclude each other")
     strong = args.total_rays > 0
     rays_per_gpu = args.rays_per_gpu or W["rays"]
+    if args.steps <= 0:
+        args.steps = 1000 if wl == "config2" else 200
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -26,19 +26,20 @@
 // Every wait is bounded (wall clock); on time-out a status word is raised and all workgroups
 // leave.  The host sizes the grid from the occupancy query (all workgroups must be resident).
 //
-// Several GPUs (one process each, rays sharded, column replicated).  The workgroup that forms a
-// rank's final row of a flux also does the node-level exchange, inside the kernel: it stores the
-// row into a host-resident segment that every rank of the node has mapped (fine-grained memory,
-// reached over PCIe; system-scope stores, release, then the rank's sequence number), waits
-// (bounded) until every rank's sequence number has reached this flux, and adds the rank rows in
-// rank order -- the same arithmetic on every rank, so the replicated columns stay bitwise
-// identical.  The exchange has the same one-pass slack as the local reduction (lagged deposit),
-// i.e. a few microseconds of PCIe latency are hidden behind the next pass.  No launch, no
-// collective kernel, no cross-stream events per RK stage.  The exchange is done by ONE extra
-// workgroup without rays (the last of the grid): if the reducing workgroup did it, the workgroup
-// that is the slowest by construction would start its next pass ~8 us later still, and that showed
-// up as +3.6 us per pass; with the exchange workgroup a multi-rank pass costs what a single-GPU
-// pass costs.
+// Several GPUs (one process each, rays sharded, column replicated).  The sum over the ranks is a step of the column
+// workgroup (persist_column_wg): it adds the reducers' group sums to this rank's row, writes that row into the slot it
+// owns in EVERY rank's exchange buffer (device-resident transport: peer writes over xGMI into HIP-IPC-mapped HBM,
+// system-scope stores, release, then its sequence number; fallback: a host-resident segment reached over PCIe), waits
+// (bounded) until every rank's sequence number in its OWN buffer has reached this flux, and adds the rank rows in rank
+// order -- the same arithmetic on every rank, so the replicated columns stay bitwise identical.  No launch, no
+// collective kernel, no cross-stream event per RK stage.  (Round 1 used a separate exchange workgroup between reducers
+// and column workgroup: one more hand-off on the reduce chain, 46.7 vs 45.0 us per step; it survives as the fallback
+// for grids without reducer workgroups, persist_exchange.)
+// Round 3 tried to shorten the reduce chain by letting every reducer own a slice of the column (rows in slice-major
+// layout, reducers advance their winds and publish their part of the table, the rank sum reducer by reducer with
+// tagged 8-byte words instead of release + flag): a pass was released 5.7 us after the last row instead of 9.2 and the
+// 1-rank exchange cost +4.8 % instead of +13 %, but config 3 ran 37.4 us per step against 33.7 (all workgroups then
+// wait for every release, phase-locked) -- kept on the branch r3-column-slice-reducers, DESIGN.md 6.
 #pragma once
 #include "ray_kernels.h"
 
@@ -55,6 +56,7 @@ __device__ __forceinline__ void setprio_rt(unsigned int v)    // s_setprio takes
 // BALANCE priorities in opts: bits 4-5 released on arrival, 6-7 had to wait, 8-9 prefetched (persist_publish)
 constexpr unsigned int PERSIST_OPT_BALANCE = 4u;    // a workgroup that finds its pass released on arrival raises its wave priority (persist_stage)
 constexpr unsigned int PERSIST_OPT_PREFETCH = 2u;   // early poll + table prefetch at the pass boundary (persist_publish)
+constexpr unsigned int PERSIST_OPT_LEANPOLL = 8u;   // wait loops look at the status word / clock every 16th poll only
 constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
 constexpr int PD_ROW = 64;               // (unused since the column workgroup does the sum over the ranks itself)
 constexpr int PD_LOCAL = 96;             // ready[PD_LOCAL]: several ranks: fluxes whose rank row is complete
@@ -221,9 +223,13 @@ __device__ __forceinline__ bool persist_wait_seen(const PersistArgsT<T> p, unsig
         if (seen > target) ok = 3;                             // bit 1: the next flux is final too, i.e. this workgroup trails
         if (seen < target) {
             ok |= 4;                                           // bit 2: this workgroup had to wait for the release
+            // (the status word and the clock are looked at every 16th poll only: as a load of its own per poll the status
+            // check doubles the round trips of the loop, i.e. the time a released pass goes unnoticed)
             const unsigned long long t0 = wall_clock64();
+            unsigned int polls = 0;
             while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                 __builtin_amdgcn_s_sleep(8);
+                if ((p.opts & PERSIST_OPT_LEANPOLL) && (++polls & 15u) != 0u) continue;
                 if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                     wall_clock64() - t0 > p.timeout_ticks) {
                     __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -323,7 +329,6 @@ __device__ __forceinline__ void persist_reduce_final(const PersistArgsT<T> p, un
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for flux f+2
         __hip_atomic_fetch_add(p.xch ? p.ready + PD_LOCAL : p.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -400,16 +405,15 @@ __device__ __forceinline__ int persist_publish(const PersistArgsT<T> p, double *
     if (tid == 0) {
         const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: rows are read with sc1 loads
-        s_flag[1] = (t == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;
+        s_flag[1] = (t % (unsigned int)(r1 - r0) == (unsigned int)(r1 - r0 - 1)) ? 1 : 0;   // (cumulative ticket: last of this flux)
     }
     __syncthreads();
     if (!s_flag[1]) return 0;
     persist_reduce_group(p, g, f, ncols, tid);
     if (tid == 0) {
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for flux f+2
         const unsigned int t2 = __hip_atomic_fetch_add(p.done2 + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        s_flag[2] = (t2 == (unsigned int)p.ngroups - 1u) ? 1 : 0;   // last group of this flux?
+        s_flag[2] = (t2 % (unsigned int)p.ngroups == (unsigned int)p.ngroups - 1u) ? 1 : 0;   // last group of this flux? (cumulative)
     }
     __syncthreads();
     if (!s_flag[2]) return 0;
@@ -433,8 +437,10 @@ __device__ __forceinline__ void persist_service(const PersistArgsT<T> p, int g, 
         if (tid == 0) {
             int ok = 1;
             const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gsize) {
+            unsigned int polls = 0;
+            while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gsize * ((f >> 1) + 1u)) {
                 __builtin_amdgcn_s_sleep(2);
+                if ((p.opts & PERSIST_OPT_LEANPOLL) && (++polls & 15u) != 0u) continue;
                 if (wall_clock64() - t0 > p.timeout_ticks ||
                     __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -448,25 +454,21 @@ __device__ __forceinline__ void persist_service(const PersistArgsT<T> p, int g, 
         __syncthreads();
         if (!s_flag[par]) return;
         persist_reduce_group(p, g, f, ncols, tid);
-        if (tid == 0) {                                       // the group sums are added by the column (one rank)
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for flux f+2
-            __hip_atomic_fetch_add(p.done2 + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // or exchange workgroup
-        }
+        // (tickets and counters are CUMULATIVE over the launch -- flux f is the (f >> 1)-th of its parity -- so nothing is
+        // ever re-armed: round 2 reset them with a relaxed store next to a relaxed add, ordered only by the pass in between)
+        if (tid == 0) __hip_atomic_fetch_add(p.done2 + par, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the column / exchange workgroup
     }
 }
 
-// Column / exchange workgroup: wait until all group sums of flux f are there, add them (`sink(col, tot)`, into LDS),
-// re-arm the counter.  Returns false after a time-out.
+// Column / exchange workgroup: wait until all group sums of flux f are there (cumulative counter) and add them
+// (`sink(col, tot)`, into LDS).  Returns false after a time-out.
 template <typename T, typename Sink>
 __device__ __forceinline__ bool persist_take_groups(const PersistArgsT<T> p, unsigned int f, int ncols, int *s_flag,
                                                     int tid, Sink sink)
 {
     const unsigned int par = f & 1u;
-    if (!persist_wait(p, (unsigned int)p.ngroups, s_flag, tid, p.done2 + par)) return false;
+    if (!persist_wait(p, (unsigned int)p.ngroups * ((f >> 1) + 1u), s_flag, tid, p.done2 + par)) return false;   // (cumulative)
     persist_sum_groups(p, f, ncols, tid, sink);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the rows have been read ...
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(p.done2 + par, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... re-arm for flux f+2
     return true;
 }
 
