@@ -23,8 +23,8 @@ struct HpropArgs {
 #ifndef HPROP_WG_PER_CU
 #define HPROP_WG_PER_CU 2
 #endif
-template <int STAGE, bool SAT>
-__global__ void __launch_bounds__(BLOCK, HPROP_WG_PER_CU) k_ray_stage_hprop(const HpropArgs h)
+template <int STAGE, bool SAT, int RPT = 2>
+__global__ void __launch_bounds__(BLOCK, RPT == 1 ? 4 : HPROP_WG_PER_CU) k_ray_stage_hprop(const HpropArgs h)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const StageArgs a = h.s;
@@ -60,25 +60,29 @@ __global__ void __launch_bounds__(BLOCK, HPROP_WG_PER_CU) k_ray_stage_hprop(cons
     DepWindow acc;
     acc.clear();
     for (int t = 0; t < a.tiles_per_block; ++t) {
-        const long long base = start + (long long)t * Real<double>::TILE;
+        const long long base = start + (long long)t * (BLOCK * RPT);
         if (base >= end) break;
-        const long long e0 = base + 2 * tid;
+        const long long e0 = base + RPT * tid;
         const unsigned int i0 = (unsigned int)(e0 * 8);
-        const bool valid[2] = {e0 < end, e0 + 1 < end};
-        double dens[2], lam[2], phi[2], rr[2], drr[2], kk[2], ll[2], mm[2], vol[2], pvf[2] = {1.0, 1.0};
-        double qd[2] = {0, 0}, qla[2] = {0, 0}, qph[2] = {0, 0}, qr[2] = {0, 0}, qk[2] = {0, 0}, ql[2] = {0, 0},
-               qm[2] = {0, 0};
+        bool valid[RPT];
+        double dens[RPT], lam[RPT], phi[RPT], rr[RPT], drr[RPT], kk[RPT], ll[RPT], mm[RPT], vol[RPT], pvf[RPT];
+        double qd[RPT], qla[RPT], qph[RPT], qr[RPT], qk[RPT], ql[RPT], qm[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            valid[r] = e0 + r < end; pvf[r] = 1.0;
+            qd[r] = 0; qla[r] = 0; qph[r] = 0; qr[r] = 0; qk[r] = 0; ql[r] = 0; qm[r] = 0;
+        }
         loadv(a.r.dens(), i0, dens); loadv(h.lam, i0, lam); loadv(h.phi, i0, phi); loadv(a.r.rr(), i0, rr);
         loadv(a.r.drr(), i0, drr); loadv(h.kk, i0, kk); loadv(h.ll, i0, ll); loadv(a.r.mm(), i0, mm);
         loadv(a.r.vol(), i0, vol);
         if (SAT) loadv(a.r.pvf(), i0, pvf);
         // (the RK registers are loaded after the physics; the kernel is latency-bound)
-        double lo[2], up[2], pay[2][2];
-        double n_dens[2], n_lam[2], n_phi[2], n_rr[2], n_kk[2], n_ll[2], n_mm[2];
-        double tend[7][2];
-        int nlo[2], nup[2];
+        double lo[RPT], up[RPT], pay[2][RPT];
+        double n_dens[RPT], n_lam[RPT], n_phi[RPT], n_rr[RPT], n_kk[RPT], n_ll[RPT], n_mm[RPT];
+        double tend[7][RPT];
+        int nlo[RPT], nup[RPT];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             double sinp, cosp;
             sincos(phi[r], &sinp, &cosp);                      // one argument reduction for both
             const double tanp = sinp / cosp;                   // (np.tan to ~1 ulp: this path is held to rtol 1e-10)
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(BLOCK, HPROP_WG_PER_CU) k_ray_stage_hprop(cons
             if (SAT) loadv(a.r.q_dens(), i0, qd);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             if (STAGE == 3) {
                 n_dens[r] = tend[0][r]; n_lam[r] = tend[1][r]; n_phi[r] = tend[2][r]; n_rr[r] = tend[3][r];
                 n_kk[r] = tend[4][r]; n_ll[r] = tend[5][r]; n_mm[r] = tend[6][r];
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(BLOCK, HPROP_WG_PER_CU) k_ray_stage_hprop(cons
                 }
             }
         }
-        deposit_tile<2, double>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
+        deposit_tile<2, double, RPT>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
                            ncp, lane, wmin, wmax, acc);
     }
     flush_window(acc, s_rows + wave * 2 * ncp, ncp, lane);

@@ -32,26 +32,30 @@ const void *column_kernel(int stage, int mode)
     }
     return nullptr;
 }
-const void *hprop_kernel(int stage, bool sat)
+template <int RPT>
+static const void *hprop_rpt(int stage, bool sat)
 {
     switch (stage) {
-    case 0: return sat ? KPTR(k_ray_stage_hprop<0, true>) : KPTR(k_ray_stage_hprop<0, false>);
-    case 1: return sat ? KPTR(k_ray_stage_hprop<1, true>) : KPTR(k_ray_stage_hprop<1, false>);
-    case 2: return sat ? KPTR(k_ray_stage_hprop<2, true>) : KPTR(k_ray_stage_hprop<2, false>);
-    case 3: return sat ? KPTR(k_ray_stage_hprop<3, true>) : KPTR(k_ray_stage_hprop<3, false>);
+    case 0: return sat ? KPTR(k_ray_stage_hprop<0, true, RPT>) : KPTR(k_ray_stage_hprop<0, false, RPT>);
+    case 1: return sat ? KPTR(k_ray_stage_hprop<1, true, RPT>) : KPTR(k_ray_stage_hprop<1, false, RPT>);
+    case 2: return sat ? KPTR(k_ray_stage_hprop<2, true, RPT>) : KPTR(k_ray_stage_hprop<2, false, RPT>);
+    case 3: return sat ? KPTR(k_ray_stage_hprop<3, true, RPT>) : KPTR(k_ray_stage_hprop<3, false, RPT>);
     }
     return nullptr;
 }
-const void *nz_kernel(int stage, bool sat)
+const void *hprop_kernel(int stage, bool sat, int rpt) { return rpt == 1 ? hprop_rpt<1>(stage, sat) : hprop_rpt<2>(stage, sat); }
+template <int RPT>
+static const void *nz_rpt(int stage, bool sat)
 {
     switch (stage) {
-    case 0: return sat ? KPTR(k_ray_stage_nz<0, true>) : KPTR(k_ray_stage_nz<0, false>);
-    case 1: return sat ? KPTR(k_ray_stage_nz<1, true>) : KPTR(k_ray_stage_nz<1, false>);
-    case 2: return sat ? KPTR(k_ray_stage_nz<2, true>) : KPTR(k_ray_stage_nz<2, false>);
-    case 3: return sat ? KPTR(k_ray_stage_nz<3, true>) : KPTR(k_ray_stage_nz<3, false>);
+    case 0: return sat ? KPTR(k_ray_stage_nz<0, true, RPT>) : KPTR(k_ray_stage_nz<0, false, RPT>);
+    case 1: return sat ? KPTR(k_ray_stage_nz<1, true, RPT>) : KPTR(k_ray_stage_nz<1, false, RPT>);
+    case 2: return sat ? KPTR(k_ray_stage_nz<2, true, RPT>) : KPTR(k_ray_stage_nz<2, false, RPT>);
+    case 3: return sat ? KPTR(k_ray_stage_nz<3, true, RPT>) : KPTR(k_ray_stage_nz<3, false, RPT>);
     }
     return nullptr;
 }
+const void *nz_kernel(int stage, bool sat, int rpt) { return rpt == 1 ? nz_rpt<1>(stage, sat) : nz_rpt<2>(stage, sat); }
 const void *nz_prepare_kernel() { return KPTR(k_nz_prepare); }
 const void *project_arrays_kernel(int np)
 {

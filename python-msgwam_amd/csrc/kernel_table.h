@@ -61,8 +61,8 @@ inline const void *persist_kernel(bool sat, bool fvec, bool direct, int nres, bo
 
 // float64-only kernels (kern_misc.hip)
 const void *column_kernel(int stage, int mode);          // k_column<STAGE, MODE>
-const void *hprop_kernel(int stage, bool sat);           // k_ray_stage_hprop<STAGE, SAT>
-const void *nz_kernel(int stage, bool sat);              // k_ray_stage_nz<STAGE, SAT> (N(z) column extension)
+const void *hprop_kernel(int stage, bool sat, int rpt = 2);   // k_ray_stage_hprop<STAGE, SAT, RPT>
+const void *nz_kernel(int stage, bool sat, int rpt = 2);      // k_ray_stage_nz<STAGE, SAT, RPT> (N(z) column extension)
 const void *nz_prepare_kernel();
 const void *project_arrays_kernel(int np);               // k_project<double, NP, true, true>
 const void *saturation_kernel();

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(BLOCK) k_xch_selftest(const XchTestArgs t)
     const int ncols = x.stride;                                // the whole row (taller than one workgroup: strided)
     int good = 1;
     for (int round = 1; round <= t.rounds; ++round) {
-        if (!xch_allsum(x, x.seq + (u64_t)round, nullptr, ncols, tid, s_flag + (round & 1),
+        if (!xch_allsum(x, x.seq + (u64_t)round, nullptr, ncols, tid, s_flag + (round & 1), [](int k) { return k; },
                         [&](int col) { return xch_test_value(x.rank, round, col); },
                         [&](int col, double tot) {
                             double want = 0.0;

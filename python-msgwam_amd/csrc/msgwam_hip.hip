@@ -173,6 +173,7 @@ struct msgw_ctx {
     int service = 1;                 // reducer workgroups beside the workers (MSGW_SERVICE=0: last arriver reduces)
     int balance = 1;                 // laggard workgroups of a CU raise their wave priority (MSGW_BALANCE=0 | 1)
     int prefetch = 1;                // early poll + table prefetch at the pass boundary of the resident-tile flavours (MSGW_PREFETCH=0 | 1)
+    int chain_rpt = 2;                   // rays per lane of the HPROP / N(z) stage kernels (MSGW_CHAIN_RPT=1 | 2; 1 measured no faster)
     int fixed_narrow_force = -1;         // MSGW_FIXED_NARROW=0 | 1 (diagnostic), read when the context is created
     int64_t fixed_narrow_max = 400000;   // fixed background: ray counts up to this run one ray per lane (launch_fixed)
     int regtiles = 4;                // most register-resident tiles per workgroup in the persistent kernel (MSGW_REGTILES=0 | 2 | 4)
@@ -967,9 +968,14 @@ HpropArgs make_hprop_args(msgw_ctx *c, double dt, unsigned flags)
     return h;
 }
 
-int launch_hprop_stage(msgw_ctx *c, int stage, const HpropArgs &h)
+// The HPROP and N(z) stage kernels also exist with ONE ray per lane (MSGW_CHAIN_RPT=1): ~half the registers, four or five
+// wavefronts per SIMD instead of two.  Measured at 1e6 rays: HPROP 144.3 vs 146.2, N(z) 124.4 vs 127.8, N(z) + saturation
+// 143.8 vs 138.9 us per step -- no gain, i.e. these kernels are not latency-bound: they stream 170-190 B per ray and
+// stage at ~85 % of the device's copy rate.  Two rays per lane (16-byte accesses) stay the default.
+int launch_hprop_stage(msgw_ctx *c, int stage, HpropArgs h)
 {
-    return launch_struct(c, hprop_kernel(stage, c->sat_online != 0), c->blocks, BLOCK, hprop_lds_bytes(c), h);
+    if (c->chain_rpt == 1) h.s.tiles_per_block *= 2;           // tiles of 256 rays
+    return launch_struct(c, hprop_kernel(stage, c->sat_online != 0, c->chain_rpt), c->blocks, BLOCK, hprop_lds_bytes(c), h);
 }
 
 // The stage kernels of the HPROP / N(z) chains reduce their flux rows inside the launch (flush_rows_group: one row in
@@ -1009,9 +1015,10 @@ NzArgs make_nz_args(msgw_ctx *c, double dt, unsigned flags)
     return h;
 }
 
-int launch_nz_stage(msgw_ctx *c, int stage, const NzArgs &h)
+int launch_nz_stage(msgw_ctx *c, int stage, NzArgs h)
 {
-    return launch_struct(c, nz_kernel(stage, c->sat_online != 0), c->blocks, BLOCK, hprop_lds_bytes(c), h);
+    if (c->chain_rpt == 1) h.s.tiles_per_block *= 2;           // tiles of 256 rays
+    return launch_struct(c, nz_kernel(stage, c->sat_online != 0, c->chain_rpt), c->blocks, BLOCK, hprop_lds_bytes(c), h);
 }
 
 int enqueue_steps_nz(msgw_ctx *c, double dt, unsigned flags, int count)
@@ -1252,6 +1259,7 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     c->cnt.elem_bytes = (int32_t)c->esz;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_FIXED_NARROW")) c->fixed_narrow_force = std::atoi(e) ? 1 : 0;
+    if (const char *e = std::getenv("MSGW_CHAIN_RPT")) c->chain_rpt = std::atoi(e) == 1 ? 1 : 2;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_BALANCE")) c->balance = std::atoi(e);
     if (const char *e = std::getenv("MSGW_PREFETCH")) c->prefetch = std::atoi(e) ? 1 : 0;
@@ -1973,7 +1981,7 @@ void xch_setup(msgw_ctx *c, const void *id128, std::string &why, int want_direct
     const int stride = ((ncols > 64 ? ncols : 64) + 7) / 8 * 8;
     const size_t flags_bytes = ((size_t)c->nranks * 64 + 4095) / 4096 * 4096;
     const size_t rows_off = XCH_FLAGS_OFF + flags_bytes;
-    const size_t rows_bytes = sizeof(double) * 2 * (size_t)c->nranks * stride;
+    const size_t rows_bytes = sizeof(double) * 2 * 2 * (size_t)c->nranks * stride;   // [2 slots][ranks][stride] x two 8-byte words per float64 (tagged granules)
     const size_t bytes = (rows_off + rows_bytes + 4095) / 4096 * 4096;
     const double join_timeout = 60.0;
     int fd = -1;

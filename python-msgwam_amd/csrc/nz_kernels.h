@@ -20,12 +20,12 @@ struct NzArgs {
     int group_reduce;                              // 1: in-kernel reduction of the flux rows (flush_rows_group)
 };
 
-template <int STAGE, bool SAT>
-__global__ void __launch_bounds__(BLOCK) k_ray_stage_nz(const NzArgs h)
+template <int STAGE, bool SAT, int RPT = 2>
+__global__ void __launch_bounds__(BLOCK, RPT == 1 ? 4 : 2) k_ray_stage_nz(const NzArgs h)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const StageArgs a = h.s;
-    constexpr int TILE = Real<double>::TILE;
+    constexpr int TILE = (BLOCK * RPT);
     const int ng = a.ng, ni = ng - 2, nc = ng - 1, ncp = ng - 2;
     double4 *s_sh = reinterpret_cast<double4 *>(lds);                     // [ni] {dudz, slope, dvdz, slope}
     double2 *s_rho2 = reinterpret_cast<double2 *>(lds + 4 * ni);          // [nc] {rhobar, slope}
@@ -58,11 +58,16 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_nz(const NzArgs h)
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = start + (long long)t * TILE;
         if (base >= end) break;
-        const long long e0 = base + 2 * tid;
+        const long long e0 = base + RPT * tid;
         const unsigned int i0 = (unsigned int)(e0 * 8);
-        const bool valid[2] = {e0 < end, e0 + 1 < end};
-        double dens[2], rr[2], drr[2], kk[2], ll[2], mm[2], dmm[2], ff[2], dkdl[2], area[2] = {1.0, 1.0};
-        double qd[2] = {0, 0}, qr[2] = {0, 0}, qdr[2] = {0, 0}, qm[2] = {0, 0}, qdm[2] = {0, 0};
+        bool valid[RPT];
+        double dens[RPT], rr[RPT], drr[RPT], kk[RPT], ll[RPT], mm[RPT], dmm[RPT], ff[RPT], dkdl[RPT], area[RPT];
+        double qd[RPT], qr[RPT], qdr[RPT], qm[RPT], qdm[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            valid[r] = e0 + r < end; area[r] = 1.0;
+            qd[r] = 0; qr[r] = 0; qdr[r] = 0; qm[r] = 0; qdm[r] = 0;
+        }
         loadv(a.r.dens(), i0, dens); loadv(a.r.rr(), i0, rr); loadv(h.drr, i0, drr); loadv(a.r.kk(), i0, kk);
         loadv(a.r.ll(), i0, ll); loadv(a.r.mm(), i0, mm); loadv(h.dmm, i0, dmm); loadv(a.r.fray(), i0, ff);
         loadv(h.dkdl, i0, dkdl);
@@ -71,11 +76,11 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_nz(const NzArgs h)
             loadv(a.r.q_rr(), i0, qr); loadv(h.q_drr, i0, qdr); loadv(a.r.q_mm(), i0, qm); loadv(h.q_dmm, i0, qdm);
             if (SAT) loadv(a.r.q_dens(), i0, qd);
         }
-        double lo[2], up[2], pay[2][2], vol[2];
-        double n_dens[2], n_rr[2], n_drr[2], n_mm[2], n_dmm[2];
-        int nlo[2], nup[2];
+        double lo[RPT], up[RPT], pay[2][RPT], vol[RPT];
+        double n_dens[RPT], n_rr[RPT], n_drr[RPT], n_mm[RPT], n_dmm[RPT];
+        int nlo[RPT], nup[RPT];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             const double f2 = ff[r] * ff[r];
             lo[r] = rr[r] - .5 * drr[r];                                            // :636, :655
             up[r] = rr[r] + .5 * drr[r];                                            // :635
@@ -156,7 +161,7 @@ __global__ void __launch_bounds__(BLOCK) k_ray_stage_nz(const NzArgs h)
                 }
             }
         }
-        deposit_tile<2, double>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
+        deposit_tile<2, double, RPT>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
                                    ncp, lane, wmin, wmax, acc);
     }
     flush_window(acc, s_rows + wave * 2 * ncp, ncp, lane);

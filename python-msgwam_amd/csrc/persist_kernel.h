@@ -75,8 +75,9 @@ struct XchArgs {
     int nranks, rank;
     int stride;                   // doubles per rank row (a multiple of 8)
     int direct;                   // 1: device-resident transport (peer_rows / peer_flags are valid)
-    double *rows;                 // [2][nranks][stride] rank rows, by parity of the sequence number (local view)
-    unsigned long long *flags;    // [nranks][8]  sequence number of the newest row a rank has published (local view)
+    double *rows;                 // [2][nranks][2 * stride] words: rank rows as tagged granules (two 8-byte words per
+                                  // float64, see st_tagged), by parity of the sequence number (local view)
+    unsigned long long *flags;    // [nranks][8]  (unused since the rows validate themselves; kept in the buffer layout)
     double *const *peer_rows;     // direct: [nranks] the `rows` of every rank's buffer as mapped in this process
     unsigned long long *const *peer_flags;   // direct: [nranks] the `flags` of every rank's buffer
     unsigned long long seq;       // sequence number of this launch's flux 0, minus 1
@@ -148,6 +149,127 @@ __device__ __forceinline__ void st_sys(double *p, double v)
                        __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- tagged granules.  A float64 is handed over as two naturally aligned 8-byte words {low half | tag << 32},
+// {high half | tag << 32}, each written by ONE 8-byte store: a word is either the old or the new one, never torn, so
+// the reader knows from the tags alone whether it holds the value it waits for.  No ordering between the words,
+// between values, or against a flag is needed (MI355X_MICROARCH.md, hand-off price list: "granule").
+typedef unsigned int u32_t;
+template <int SCOPE>
+__device__ __forceinline__ void st_tagged(u64_t *p, double v, u32_t tag)
+{
+    const u64_t b = (u64_t)__double_as_longlong(v), t = (u64_t)tag << 32;
+    __hip_atomic_store(p, (b & 0xffffffffull) | t, __ATOMIC_RELAXED, SCOPE);
+    __hip_atomic_store(p + 1, (b >> 32) | t, __ATOMIC_RELAXED, SCOPE);
+}
+template <int SCOPE>
+__device__ __forceinline__ void ld_words(const u64_t *p, u64_t &a, u64_t &b)
+{
+    a = __hip_atomic_load(p, __ATOMIC_RELAXED, SCOPE);
+    b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, SCOPE);
+}
+__device__ __forceinline__ bool words_ok(u64_t a, u64_t b, u32_t tag) { return (u32_t)(a >> 32) == tag && (u32_t)(b >> 32) == tag; }
+__device__ __forceinline__ double words_value(u64_t a, u64_t b) { return __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32))); }
+// one value, read until it carries `tag` (bounded; false after a time-out or when another wait has raised `status`)
+template <int SCOPE>
+__device__ __forceinline__ bool ld_tagged_wait(const u64_t *p, u32_t tag, u64_t a, u64_t b, const int *status,
+                                               u64_t timeout_ticks, double &v)
+{
+    if (!words_ok(a, b, tag)) {
+        const u64_t t0 = wall_clock64();
+        do {
+            __builtin_amdgcn_s_sleep(1);
+            ld_words<SCOPE>(p, a, b);
+            if (words_ok(a, b, tag)) break;
+            if ((status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ||
+                wall_clock64() - t0 > timeout_ticks)
+                return false;
+        } while (true);
+    }
+    v = words_value(a, b);
+    return true;
+}
+// n values src[2i], src[2i+1] -> sink(i, value): every thread fetches its own entries (two in flight) until they carry
+// `tag`.  Returns this THREAD's success; the caller agrees on it across the workgroup (__syncthreads_or).
+template <int SCOPE, typename Sink>
+__device__ __forceinline__ bool sweep_tagged(const u64_t *src, int n, u32_t tag, int tid, const int *status,
+                                             u64_t timeout_ticks, Sink sink)
+{
+    for (int i = tid; i < n; i += 2 * BLOCK) {                // (one trip for the default column's table: 396 values)
+        const int i2 = i + BLOCK;
+        const bool h2 = i2 < n;
+        u64_t a0, b0, a1, b1;
+        ld_words<SCOPE>(src + 2 * (size_t)i, a0, b0);
+        ld_words<SCOPE>(src + 2 * (size_t)(h2 ? i2 : i), a1, b1);
+        double v0, v1;
+        if (!ld_tagged_wait<SCOPE>(src + 2 * (size_t)i, tag, a0, b0, status, timeout_ticks, v0)) return false;
+        sink(i, v0);
+        if (h2) {
+            if (!ld_tagged_wait<SCOPE>(src + 2 * (size_t)i2, tag, a1, b1, status, timeout_ticks, v1)) return false;
+            sink(i2, v1);
+        }
+    }
+    return true;
+}
+
+// Node-level sum of one row per rank (see XchArgs).  `mine(col)` is this rank's value of column `col`, `sink(col, tot)`
+// receives the sum over the ranks, added in rank order (thread tid handles columns tid, tid + BLOCK, ...: columns taller
+// than one workgroup); returns false after a time-out (workgroup-uniform).  Rows travel as tagged granules (tag = the low
+// half of the sequence number): a rank writes its row into the slot it owns in every rank's buffer -- one posted write
+// per word and peer, nothing is read remotely -- and polls the rows of all ranks in its LOCAL buffer.  Round 2 published a
+// row with release fence + sequence flag and read it after a flag poll: three more serial steps per flux on a reduce
+// chain that has one pass of slack (1-rank communicator: +13 % per step).
+// Slots alternate with the parity of `seq`: a rank rewrites a slot for seq + 2 only after it has finished the sum of
+// seq + 1, which needed every rank's row of seq + 1, which that rank wrote after reading this slot's seq.
+// `nitems` items k; item k is column colmap(k) of the rank rows (several workgroups may share a buffer, each summing
+// its own columns; two of them may write the same column -- with the same value).
+template <typename ColMap, typename Mine, typename Sink>
+__device__ __forceinline__ bool xch_allsum(const XchArgs x, u64_t seq, int *status, int nitems, int tid, int *s_flag,
+                                           ColMap colmap, Mine mine, Sink sink)
+{
+    constexpr int SYS = __HIP_MEMORY_SCOPE_SYSTEM;
+    if (!x.direct) return xch_allsum_flags(x, seq, status, nitems, tid, s_flag, mine, sink);   // (identity column map there)
+    const u32_t tag = (u32_t)seq;
+    const size_t slot_off = 2 * (size_t)(seq & 1ull) * x.nranks * x.stride;           // in words
+    u64_t *rows = reinterpret_cast<u64_t *>(x.rows);
+    for (int k = tid; k < nitems; k += BLOCK) {
+        const double m = mine(k);
+        const size_t off = slot_off + 2 * ((size_t)x.rank * x.stride + colmap(k));
+        if (x.direct) {                                       // my row into the slot I own in every rank's buffer
+            for (int j = 0; j < x.nranks; ++j) st_tagged<SYS>(reinterpret_cast<u64_t *>(x.peer_rows[j]) + off, m, tag);
+        } else {
+            st_tagged<SYS>(rows + off, m, tag);
+        }
+    }
+    bool ok = true;
+    for (int k = tid; k < nitems && ok; k += BLOCK) {
+        const int col = colmap(k);
+        double tot = 0.0;
+        for (int r0 = 0; r0 < x.nranks && ok; r0 += 8) {      // eight ranks' words in flight
+            u64_t a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = min(r0 + u, x.nranks - 1);
+                ld_words<SYS>(rows + slot_off + 2 * ((size_t)r * x.stride + col), a[u], b[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (r0 + u < x.nranks && ok) {
+                    double v;
+                    ok = ld_tagged_wait<SYS>(rows + slot_off + 2 * ((size_t)(r0 + u) * x.stride + col), tag, a[u], b[u], status,
+                                             x.timeout_ticks, v);
+                    if (ok) tot = tot + v;                    // rank order
+                }
+            }
+        }
+        if (ok) sink(k, tot);
+    }
+    if (__syncthreads_or(ok ? 0 : 1)) {
+        if (tid == 0 && status) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    return true;
+}
+
 // Wave 0: every lane r < nranks polls rank r's sequence number until it reaches `seq` (bounded).
 __device__ __forceinline__ bool xch_wait_all(const u64_t *flags, int nranks, u64_t seq, int *status,
                                              u64_t timeout_ticks, int lane)
@@ -171,12 +293,13 @@ __device__ __forceinline__ bool xch_wait_all(const u64_t *flags, int nranks, u64
     return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
 }
 
-// Node-level sum of one row per rank (see XchArgs).  `mine(col)` is this rank's value of column `col`, `sink(col, tot)`
+// Round 2's protocol, kept for the HOST-SEGMENT transport (rows and flags in host memory, every poll a PCIe round trip:
+// there a waiting rank should poll one 8-byte flag per rank, not the rows).  Node-level sum of one row per rank (see XchArgs).  `mine(col)` is this rank's value of column `col`, `sink(col, tot)`
 // receives the sum over the ranks (thread tid handles columns tid, tid + BLOCK, ...: columns taller than one workgroup);
 // returns false after a time-out.  s_flag: an LDS word not used by other hand-offs.
 template <typename Mine, typename Sink>
-__device__ __forceinline__ bool xch_allsum(const XchArgs x, u64_t seq, int *status, int ncols, int tid, int *s_flag,
-                                           Mine mine, Sink sink)
+__device__ __forceinline__ bool xch_allsum_flags(const XchArgs x, u64_t seq, int *status, int ncols, int tid, int *s_flag,
+                                                 Mine mine, Sink sink)
 {
     const size_t slot_off = (size_t)(seq & 1ull) * x.nranks * x.stride;
     for (int col = tid; col < ncols; col += BLOCK) {
@@ -490,7 +613,7 @@ __device__ __forceinline__ void persist_exchange(const PersistArgsT<T> p, int *s
         for (int col = tid; col < ncols; col += BLOCK) mine[col] = ld_agent(flux_local + (size_t)par * ncols + col);
         // (a thread only ever reads back the columns it staged itself: no barrier needed in between)
         double *dst = p.flux2 + (size_t)par * ncols;
-        if (!xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, s_flag + 2 + par,
+        if (!xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, s_flag + 2 + par, [](int k) { return k; },
                         [&](int col) { return mine[col]; }, [&](int col, double tot) { st_agent(dst + col, tot); })) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -572,7 +695,7 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgsT<T> p, const
         // separate exchange workgroup cost one more hand-off per flux on the critical reduce chain: 46.7 vs 45.0 us
         // per step with a 1-rank communicator)
         if (!persist_take_groups(p, f, ncols, L.flag, tid, [&](int col, double tot) { L.F[slot(col)] = tot; })) return;
-        if (p.xch && !xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, L.flag + 4 + (f & 1u),
+        if (p.xch && !xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, L.flag + 4 + (f & 1u), [](int k) { return k; },
                                  [&](int col) { return L.F[slot(col)]; },
                                  [&](int col, double tot) { L.F[slot(col)] = tot; })) return;
         persist_column(p, L, f + 1u, (int)(f % 3u), tid, true);

@@ -416,15 +416,14 @@ __device__ __forceinline__ void flush_window(DepWindow &W, double *row, int ncp,
     W.clear();
 }
 
-template <int NP, typename T>
-__device__ __forceinline__ void deposit_tile(const T (&lo)[Real<T>::RPT], const T (&up)[Real<T>::RPT],
-                                             const int (&nlo)[Real<T>::RPT], const int (&nup)[Real<T>::RPT],
-                                             const T (&vol)[Real<T>::RPT], const T (&pay)[NP][Real<T>::RPT],
+template <int NP, typename T, int RPT = Real<T>::RPT>
+__device__ __forceinline__ void deposit_tile(const T (&lo)[RPT], const T (&up)[RPT],
+                                             const int (&nlo)[RPT], const int (&nup)[RPT],
+                                             const T (&vol)[RPT], const T (&pay)[NP][RPT],
                                              const T *sG, T dz, T cdz, int ok,
                                              double *row, int ncp, int lane, int &wmin, int &wmax,
                                              DepWindow &W)
 {
-    constexpr int RPT = Real<T>::RPT;
     int mylo = INT_MAX, myhi = INT_MIN;
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
