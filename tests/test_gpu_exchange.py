@@ -193,7 +193,7 @@ def test_config4_shard_size_through_the_exchange_vs_c_oracle(monkeypatch, transp
     assert not np.array_equal(got[9], st[9])
 
 
-def _rehearse_bench(extra):
+def _rehearse_bench(extra, size=("--rays-per-gpu", "60000")):
     import json
     import socket
     with socket.socket() as sk:                        # a free rendezvous port
@@ -202,13 +202,24 @@ def _rehearse_bench(extra):
     root = os.path.join(HERE, "..")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
-           "--warmup", "2", "--backend", "gloo", "--share-gpu", "--rays-per-gpu", "60000"] + extra
+           "--warmup", "2", "--backend", "gloo", "--share-gpu"] + list(size) + extra
     r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
     lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
     assert len(lines) == 1, out[-3000:]                # rank 0 only
     return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_rehearsal():
+    """"also run at 1, 2, 4 GPUs with the same total N".  `--total-rays` divides one ray set over
+    the ranks (the line then says "scaling": "strong"); with N > 1 and no --workload the bench runs config 4."""
+    d = _rehearse_bench(["--total-rays", "100001"], size=())
+    assert d["scaling"] == "strong" and d["n_gpus"] == 2
+    assert d["config"]["rays_total"] == 100001 and d["config"]["rays_per_gpu"] == 50000
+    assert d["config"]["workload"].startswith("config4") and d["dtype"] == "f64"
+    assert d["config"]["launch_ray_workgroups"] > 0 and d["config"]["launch_workgroups"] > d["config"]["launch_ray_workgroups"]
+    assert d["state_finite"] is True and d["value"] > 0
 
 
 def test_bench_falls_back_to_the_next_transport_when_the_exchange_fails_at_run_time():

@@ -6,7 +6,7 @@ set -u
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof/$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 SCRIPT=$ROOT/$1; shift
 cd /tmp && export TMPDIR=/tmp
 echo "python3 $SCRIPT $*" > "$OUT/command.txt"
