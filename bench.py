@@ -401,7 +401,7 @@ def main():
         big = measure(4 * rays_per_gpu, ks, max(args.warmup // 4, 5), "none", 3)
         v = big["n_total"] * ks / float(np.median(big["walls"]))
         extra = {"rays_per_gpu": big["n_total"], "value": v,
-                 "effective_algorithmic_frac_of_hbm_peak": v * W["bytes"] / 1e9 / HBM_PEAK_GBS,
+                 "effective_algorithmic_over_hbm_peak": v * W["bytes"] / 1e9 / HBM_PEAK_GBS,
                  "note": "same workload at 4x the rays: the streamed working set no longer fits the 256 MiB Infinity Cache"}
         lt = measure(rays_per_gpu, args.steps, args.warmup, "none", 0, pre_steps=args.late_steps)
         lw = np.array(lt["walls"])
@@ -475,7 +475,7 @@ def main():
                 "hbm_counter_frac": None if traffic is None else traffic / ksec / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": per_launch_bytes,
                 "effective_algorithmic_gbs": eff,
-                "effective_algorithmic_frac_of_hbm_peak": eff / HBM_PEAK_GBS,
+                "effective_algorithmic_over_hbm_peak": eff / HBM_PEAK_GBS,
                 "effective_algorithmic_is": "SURVEY 8d words per ray-step x rays x steps of one launch / the launch's HIP-event "
                                             "duration: an EFFECTIVE rate, not a utilisation (a kernel that keeps the evolving "
                                             "state in registers moves fewer bytes than that, so it can exceed the HBM peak)",
@@ -568,7 +568,7 @@ def main():
                        **({"one_ray_per_lane": bool(narrow)} if wl == "config2" else {}),
                        "kernel_src_digest": digest,
                        "timing": "median of `repeats` identical experiments (fresh state, `warmup` steps, then `steps` steps timed)"},
-            "effective_algorithmic_frac_of_hbm_peak": value * bps / 1e9 / (HBM_PEAK_GBS * world),
+            "effective_algorithmic_over_hbm_peak": value * bps / 1e9 / (HBM_PEAK_GBS * world),
             "state_finite": finite,
             "roofline": roofline,
         }
