@@ -207,6 +207,8 @@ def main():
     if args.total_rays and args.rays_per_gpu:
         raise SystemExit("--total-rays and --rays-per-gpu exclude each other")
     strong = args.total_rays > 0
+    if (args.total_rays or 0) % 400 or (args.rays_per_gpu or 0) % 400:
+        raise SystemExit("ray counts must be multiples of 400 (the synthetic spectrum tiles 100 height x 4 azimuth bins)")
     rays_per_gpu = args.rays_per_gpu or W["rays"]
     if args.steps <= 0:
         args.steps = 1000 if wl == "config2" else 200

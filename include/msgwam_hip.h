@@ -94,6 +94,8 @@ typedef struct {
     int32_t launch_ray_workgroups; /* of those, the workgroups that own rays */
     int32_t launch_reducers;     /* persistent kernel: reducer workgroups of the last launch (0: the last arriver reduces) */
     int32_t fixed_narrow;        /* fixed-background kernel: 1 = one ray per lane, one wavefront per workgroup */
+    int32_t carried_flux;        /* 1: the last persistent launch took the flux of its initial state from the previous launch
+                                    (same resident state, same kernel flavour) instead of a deposit-only pre-pass */
     double  algorithmic_bytes_total; /* SURVEY 8d bytes moved since create: words per ray-step of the path taken (35 coupled,
                                     45 with online saturation, 6 fixed background; 71 HPROP, 63 N(z)) x elem_bytes x rays
                                     x steps -- the yardstick of the roofline, not a hardware counter */

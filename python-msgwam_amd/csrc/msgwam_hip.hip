@@ -182,6 +182,13 @@ struct msgw_ctx {
     int *pstatus = nullptr;          // raised by a persistent launch whose bounded wait timed out; sticky until the next
                                      // msgw_upload_rays, read back at the next blocking call (check_status)
     bool status_armed = false;       // a persistent launch has been enqueued since the last check
+    int *pstatus_host = nullptr;     // host-mapped copy of the status word (hipHostMalloc): read after a sync, no D2H copy
+    int *pstatus_host_dev = nullptr; // ... as the kernel sees it
+    double *fcarry = nullptr;        // [2*(ng-2)] flux row of the final state of the last persistent launch (persist_kernel.h)
+    int carry = 1;                   // MSGW_CARRY=0 (diagnostic, read when the context is created): always run the pre-pass
+    unsigned long long carry_key = 0;    // != 0: fcarry is F_0 of the resident state for a launch of this flavour key
+    unsigned long long plan_key = 0;     // the cached launch plan (plan_persist costs three occupancy queries per call)
+    std::vector<char> plan_blob;
     double *flux2 = nullptr;         // [2][ncols] final flux rows of the persistent kernel
     double *shtab = nullptr;         // [2][ng-2] double4 shear tables published by the column workgroup
     unsigned long long *pstamps = nullptr;   // diagnostic builds only
@@ -388,6 +395,16 @@ int ensure_groups(msgw_ctx *c)
         HIPCHK(c, hipMalloc(&c->pdone, sizeof(unsigned int) * PDONE_WORDS));
         HIPCHK(c, hipMalloc(&c->pstatus, 128));
         HIPCHK(c, hipMemsetAsync(c->pstatus, 0, 128, c->stream));
+        HIPCHK(c, hipMalloc(&c->fcarry, sizeof(double) * (size_t)2 * (c->ng - 2)));
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->pstatus_host), 128, hipHostMallocMapped) == hipSuccess) {
+            std::memset(c->pstatus_host, 0, 128);
+            if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->pstatus_host_dev), c->pstatus_host, 0) != hipSuccess) {
+                (void)hipGetLastError(); (void)hipHostFree(c->pstatus_host);
+                c->pstatus_host = nullptr; c->pstatus_host_dev = nullptr;
+            }
+        } else {
+            (void)hipGetLastError(); c->pstatus_host = nullptr;
+        }
         HIPCHK(c, hipMalloc(&c->flux2, sizeof(double) * (size_t)4 * 2 * (c->ng - 2)));   // [2] final + [2] this rank's
         HIPCHK(c, hipMalloc(&c->shtab, sizeof(double) * (size_t)2 * 4 * (c->ng - 2)));
     }
@@ -629,12 +646,18 @@ int check_status(msgw_ctx *c)
 {
     if (!c->status_armed || !c->pstatus) return MSGW_OK;
     int status = 0;
-    HIPCHK(c, hipMemcpyAsync(&status, c->pstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->pstatus_host) {                                     // the kernel also raises the word in host-mapped memory
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        status = *reinterpret_cast<volatile int *>(c->pstatus_host);
+    } else {
+        HIPCHK(c, hipMemcpyAsync(&status, c->pstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->status_armed = false;
     if (status == 0) return MSGW_OK;
     c->persist = 0;                                            // the per-stage kernels are used from now on
     c->have_rays = false;
+    c->carry_key = 0;
     if (c->nranks > 1 || c->force_coll)
         return fail(c, MSGW_ERR_HIP, "persistent RK3 kernel timed out in the node-level flux exchange (a rank "
                     "died, or the ranks did not call msgw_step alike); state is invalid, upload the rays again");
@@ -733,14 +756,27 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     bool want = c->persist && can_fuse && (!multi || c->xch_ok);
     PersistPlan pl;
     bool fits = false;
-    if (want && c->regtiles > 3)                               // first choice: four register-resident tiles,
+    // the plan of the previous call when nothing it depends on has changed (each plan_persist is up to two occupancy
+    // queries and a function-attribute call: ~15 us per msgw_step call, the size of a 20-step call's launch latency)
+    const unsigned long long pkey = 0x9e3779b97f4a7c15ull * (unsigned long long)(c->n + 1) ^
+        ((unsigned long long)mode | (unsigned long long)rl << 2 | (unsigned long long)multi << 3 | (unsigned long long)c->fvec << 4 |
+         (unsigned long long)c->f32 << 5 | (unsigned long long)c->regtiles << 6 | (unsigned long long)c->service << 10 |
+         (unsigned long long)c->tenants << 11 | (unsigned long long)c->blocks_per_cu << 20 | (unsigned long long)c->ng << 32 | 1ull << 63);
+    const bool cached = want && c->plan_key == pkey && c->plan_blob.size() == sizeof(PersistPlan);
+    if (cached) { std::memcpy(&pl, c->plan_blob.data(), sizeof pl); fits = true; }
+    if (want && !cached && c->regtiles > 3)                    // first choice: four register-resident tiles,
         if (int rc = plan_persist<T>(c, 4, mode, rl, multi, pl, &fits)) return rc;
-    if (want && c->regtiles > 2 && !fits)                      // three (variants that do not have four),
+    if (want && !cached && c->regtiles > 2 && !fits)           // three (variants that do not have four),
         if (int rc = plan_persist<T>(c, 3, mode, rl, multi, pl, &fits)) return rc;
-    if (want && c->regtiles && !fits)                          // then two,
+    if (want && !cached && c->regtiles && !fits)               // then two,
         if (int rc = plan_persist<T>(c, 2, mode, rl, multi, pl, &fits)) return rc;
-    if (want && !fits)
+    if (want && !cached && !fits)
         if (int rc = plan_persist<T>(c, 0, mode, rl, multi, pl, &fits)) return rc;
+    if (want && fits && !cached) {
+        c->plan_blob.resize(sizeof(PersistPlan));
+        std::memcpy(c->plan_blob.data(), &pl, sizeof pl);
+        c->plan_key = pkey;
+    }
     want = want && fits;
     // several ranks: either every rank launches the persistent kernel or none does (a rank that declined while
     // its peers spin in the exchange would leave them to their time-out)
@@ -778,6 +814,16 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.shtab = c->shtab;
     pa.ready = c->pdone;
     pa.status = c->pstatus;
+    pa.status_host = c->pstatus_host_dev;
+    // F_0 carried over from the previous launch: same ray state (nothing uploaded, no step through another path since),
+    // same kernel flavour (the streamed tiles' cg_rr in memory belongs to it), reducer workgroups on
+    const unsigned long long ckey = 1ull | ((unsigned long long)pl.nres << 1) | ((unsigned long long)mode << 5) |
+                                    ((unsigned long long)rl << 8) | ((unsigned long long)c->fvec << 9) |
+                                    ((unsigned long long)c->f32 << 10) | ((unsigned long long)(flags & 0xffu) << 16);
+    pa.fcarry = (pl.nservice && c->carry) ? c->fcarry : nullptr;
+    pa.carry_in = (pa.fcarry && c->carry_key == ckey) ? 1 : 0;
+    c->carry_key = pa.fcarry ? ckey : 0;
+    c->cnt.carried_flux = pa.carry_in;
     pa.done2 = c->pdone + 32;
     pa.grp_cnt2 = c->pdone + 128;
 #ifdef MSGW_STAMP
@@ -1089,6 +1135,7 @@ int step_impl(msgw_ctx *c, double dt, int nsteps, unsigned gflags, bool eager, b
         c->cnt.persist_resident_tiles = 0;
         if (int rc = run_persistent<T>(c, dt, gflags, nsteps, time_kernels, &used)) return rc;
         if (used) done = nsteps;
+        else c->carry_key = 0;                                 // another path advances the state: no flux carried over
     }
     if (done < nsteps && !eager && nsteps >= c->graph_steps) {
         if (!c->gexec || c->g_dt != dt || c->g_flags != gflags || c->g_n != c->n || c->g_steps != c->graph_steps) {
@@ -1259,6 +1306,7 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     c->cnt.elem_bytes = (int32_t)c->esz;
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_FIXED_NARROW")) c->fixed_narrow_force = std::atoi(e) ? 1 : 0;
+    if (const char *e = std::getenv("MSGW_CARRY")) c->carry = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_CHAIN_RPT")) c->chain_rpt = std::atoi(e) == 1 ? 1 : 2;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_BALANCE")) c->balance = std::atoi(e);
@@ -1295,6 +1343,8 @@ int msgw_destroy(msgw_ctx *c)
     if (c->grp_rows2) (void)hipFree(c->grp_rows2);
     if (c->pdone) (void)hipFree(c->pdone);
     if (c->pstatus) (void)hipFree(c->pstatus);
+    if (c->pstatus_host) (void)hipHostFree(c->pstatus_host);
+    if (c->fcarry) (void)hipFree(c->fcarry);
     if (c->flux2) (void)hipFree(c->flux2);
     if (c->shtab) (void)hipFree(c->shtab);
     if (c->grp_part2) (void)hipFree(c->grp_part2);
@@ -1313,6 +1363,7 @@ int msgw_destroy(msgw_ctx *c)
 int msgw_set_config(msgw_ctx *c, double bvf, double f0, double kappa, int saturate_online, int hprop)
 {
     if (!c) return MSGW_ERR_ARG;
+    c->carry_key = 0;                                          // (the flux of the resident state depends on bvf and f)
     HIPCHK(c, hipSetDevice(c->device));
     if (hprop && c->f32)
         return fail(c, MSGW_ERR_UNSUP, "HPROP_GLOBAL = True is float64 only (create the context without MSGW_DTYPE_F32)");
@@ -1349,6 +1400,7 @@ int msgw_set_column(msgw_ctx *c, const double *grid, const double *grids, const 
     HIPCHK(c, hipStreamSynchronize(c->stream));      // host buffers are the caller's
     c->dzg = grid[1] - grid[0];                      // np.diff(grid[:2])[0]  (lib/libprop.py:349, :662)
     c->dzs = grids[1] - grids[0];                    // the same on grids     (:123 with G = grids)
+    c->plan_key = 0;                                 // (the launch plan looks at the grid spacing)
     c->xg0 = grid[1];
     c->gs0 = grids[0];
     c->z_bot = grid[0]; c->z_top = grid[ng - 1];     // MSGW_RELAUNCH: the column's extent
@@ -1429,7 +1481,9 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
         if (int rc2 = c->f32 ? fill_padding<float>(c, n, n_pad) : fill_padding<double>(c, n, n_pad)) return rc2;
     if (c->pstatus) HIPCHK(c, hipMemsetAsync(c->pstatus, 0, 128, c->stream));   // a fresh state: forget an old time-out
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->pstatus_host) *reinterpret_cast<volatile int *>(c->pstatus_host) = 0;
     c->status_armed = false;
+    c->carry_key = 0;                                          // a new ray state: no flux carried over
     // a single latitude for all rays (the 1-D column case, raytracer.py:87) keeps f in a scalar
     bool uni = true;
     for (int64_t i = 1; i < n && uni; ++i) uni = (std::memcmp(&fray[i], &fray[0], sizeof(double)) == 0);
@@ -1479,6 +1533,7 @@ int msgw_download_hprop(msgw_ctx *c, int64_t n, int tendencies, double *lam, dou
 int msgw_set_bvf_column(msgw_ctx *c, const double *bvf)
 {
     if (!c) return MSGW_ERR_ARG;
+    c->carry_key = 0;
     HIPCHK(c, hipSetDevice(c->device));
     if (!bvf) {                                                // back to the scalar of msgw_set_config
         c->nz = 0;
@@ -1546,6 +1601,7 @@ int msgw_set_tuning(msgw_ctx *c, int blocks_per_cu, int graph_steps)
         return fail(c, MSGW_ERR_ARG, "blocks_per_cu in [1,64], graph_steps in [0,64]");
     c->blocks_per_cu = blocks_per_cu;
     c->graph_steps = graph_steps;
+    c->plan_key = 0;
     drop_graph(c);
     if (c->have_rays) {
         geometry(c, c->n);
@@ -1578,6 +1634,7 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
             return fail(c, MSGW_ERR_UNSUP, "the fused direct saturation and the relaunch extension are not "
                         "available with HPROP on (use msgw_saturation on downloaded arrays)");
         c->cnt.persist_steps = 0;
+        c->carry_key = 0;
         if (int rc = enqueue_steps_hprop(c, dt, gflags, nsteps)) return rc;
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
@@ -1589,6 +1646,7 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
             return fail(c, MSGW_ERR_UNSUP, "the fused direct saturation and the relaunch extension are not "
                         "available with an N(z) column");
         c->cnt.persist_steps = 0;
+        c->carry_key = 0;
         if (int rc = enqueue_steps_nz(c, dt, gflags, nsteps)) return rc;
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
@@ -2162,6 +2220,7 @@ int msgw_comm_init(msgw_ctx *c, const void *id128, int rank, int nranks)
     c->rank = rank;
     c->nranks = nranks;
     c->cnt.nranks = nranks;
+    c->plan_key = 0;
     // MSGW_FORCE_COLLECTIVE=1: run the all-reduce chain even for a 1-rank communicator, so that the
     // multi-GPU code path (reduce -> ncclAllReduce -> 1-row prologue) can be tested on a 1-GPU box
     if (const char *e = std::getenv("MSGW_FORCE_COLLECTIVE")) c->force_coll = std::atoi(e) != 0;

@@ -105,6 +105,12 @@ struct PersistArgsT {
     double *shtab;                // [2][ng-2] double4: shear table of a pass, by flux parity (column workgroup)
     unsigned int opts;            // PERSIST_OPT_*
     int *status;                  // 0 ok, 1 a wait timed out
+    int *status_host;             // the same word in host-mapped memory (written once when a wait times out; read by the
+                                  // host after the launch without a device-to-host copy), or nullptr
+    double *fcarry;               // [2*(ng-2)] this rank's flux row of the FINAL state of the launch (written by the column
+                                  // workgroup), = F_0 of the next launch when nothing touches the state in between
+    int carry_in;                 // 1: F_0 is in fcarry (left by the previous launch): no deposit-only pre-pass, the reducers
+                                  // start at flux 1 (reducer workgroups only)
     unsigned long long timeout_ticks;   // wall_clock64 ticks (100 MHz)
     const XchArgs *xch;           // several ranks: the node-level exchange runs (one extra workgroup) with this transport
                                   // (device memory, written once when the communicator is set up); else nullptr
@@ -356,6 +362,7 @@ __device__ __forceinline__ bool persist_wait_seen(const PersistArgsT<T> p, unsig
                 if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                     wall_clock64() - t0 > p.timeout_ticks) {
                     __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p.status_host) __hip_atomic_store(p.status_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     ok = 0;
                     break;
                 }
@@ -554,19 +561,23 @@ __device__ __forceinline__ void persist_service(const PersistArgsT<T> p, int g, 
     const int ncols = 2 * (p.s.ng - 2);
     const unsigned int nflux = 3u * (unsigned int)p.nsteps + 1u;
     const unsigned int gsize = (unsigned int)(min(p.nworkers, (g + 1) * p.s.grp_size) - g * p.s.grp_size);
-    for (unsigned int f = 0; f < nflux; ++f) {
+    // (with F_0 carried over from the previous launch nobody publishes flux 0: the fluxes of parity 0 then start at 2)
+    const unsigned int skip0 = p.carry_in ? 1u : 0u;
+    for (unsigned int f = skip0; f < nflux; ++f) {
         const unsigned int par = f & 1u;
+        const unsigned int kth = (f >> 1) + 1u - (par == 0u ? skip0 : 0u);   // flux f is the kth of its parity in this launch
         unsigned int *ticket = p.grp_cnt2 + ((size_t)par * PERSIST_GROUPS + g) * TICKET_STRIDE;
         if (tid == 0) {
             int ok = 1;
             const unsigned long long t0 = wall_clock64();
             unsigned int polls = 0;
-            while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gsize * ((f >> 1) + 1u)) {
+            while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gsize * kth) {
                 __builtin_amdgcn_s_sleep(2);
                 if ((p.opts & PERSIST_OPT_LEANPOLL) && (++polls & 15u) != 0u) continue;
                 if (wall_clock64() - t0 > p.timeout_ticks ||
                     __hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (p.status_host) __hip_atomic_store(p.status_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     ok = 0;
                     break;
                 }
@@ -590,7 +601,8 @@ __device__ __forceinline__ bool persist_take_groups(const PersistArgsT<T> p, uns
                                                     int tid, Sink sink)
 {
     const unsigned int par = f & 1u;
-    if (!persist_wait(p, (unsigned int)p.ngroups * ((f >> 1) + 1u), s_flag, tid, p.done2 + par)) return false;   // (cumulative)
+    const unsigned int kth = (f >> 1) + 1u - ((par == 0u && p.carry_in) ? 1u : 0u);   // (cumulative; see persist_service)
+    if (!persist_wait(p, (unsigned int)p.ngroups * kth, s_flag, tid, p.done2 + par)) return false;
     persist_sum_groups(p, f, ncols, tid, sink);
     return true;
 }
@@ -694,7 +706,9 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgsT<T> p, const
         // (into L.F); several ranks: that is this rank's row, and the sum over the ranks follows at once (a
         // separate exchange workgroup cost one more hand-off per flux on the critical reduce chain: 46.7 vs 45.0 us
         // per step with a 1-rank communicator)
-        if (!persist_take_groups(p, f, ncols, L.flag, tid, [&](int col, double tot) { L.F[slot(col)] = tot; })) return;
+        if (f == 0u && p.carry_in) {                           // F_0 = the final flux of the previous launch
+            for (int col = tid; col < ncols; col += BLOCK) L.F[slot(col)] = p.fcarry[col];
+        } else if (!persist_take_groups(p, f, ncols, L.flag, tid, [&](int col, double tot) { L.F[slot(col)] = tot; })) return;
         if (p.xch && !xch_allsum(x, x.seq + f + 1ull, p.status, ncols, tid, L.flag + 4 + (f & 1u), [](int k) { return k; },
                                  [&](int col) { return L.F[slot(col)]; },
                                  [&](int col, double tot) { L.F[slot(col)] = tot; })) return;
@@ -715,6 +729,11 @@ __device__ __forceinline__ void persist_column_wg(const PersistArgsT<T> p, const
         p.dudz[i] = t.x; p.dvdz[i] = t.z;
         if (i < ni - 1) { p.slu[i] = t.y; p.slv[i] = t.w; }
     }
+    // The flux of the FINAL state (published by the last pass, reduced by the reducers like any other): this rank's row
+    // of it is F_0 of the next launch, which then needs no deposit-only pre-pass -- one streaming pass over all rays and
+    // one trip down the reduce chain less per msgw_step call (bench.py's driver arguments time 20-step calls)
+    if (p.fcarry)
+        (void)persist_take_groups(p, nflux, ncols, L.flag, tid, [&](int col, double tot) { p.fcarry[col] = tot; });
 }
 
 template <typename T, int STAGE, bool SAT, bool FVEC, bool DIRECT, int NRES, bool RL>
@@ -854,14 +873,17 @@ __global__ void __launch_bounds__(BLOCK, NRES > 0 ? ((MSGW_EXP3 && NRES == 2) ? 
     }
     if constexpr (LEAN) stage_rho(C, a.c, nc, tid, true);     // (after the tables: du, dv lived in the density table's LDS)
 
-    // deposit-only pre-pass: F_0 = wave_projection(state_0)
+    // deposit-only pre-pass: F_0 = wave_projection(state_0) -- unless the previous launch left it behind (carry_in: the
+    // cg_rr of the streamed tiles of the two-resident-tile flavours is in memory too, stored by that launch's last pass)
     {
         for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;
         __syncthreads();
-        const StageLds<T> SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
-        // (with resident tiles: also leaves cg_rr of the initial state of the streamed tiles in memory)
-        deposit_pass<T, FVEC, (NRES > 0 && NRES <= CGMEM_MAX_NRES && !SAT)>(a, SL, start, end, tid, wave, lane, start + (long long)NRES * TILE);
-        persist_publish(p, L.rows, ncp, L.flag, tid, 0u);
+        if (!p.carry_in) {
+            const StageLds<T> SL{L.sh, L.rho2, L.xg, L.gs, L.rows};
+            // (with resident tiles: also leaves cg_rr of the initial state of the streamed tiles in memory)
+            deposit_pass<T, FVEC, (NRES > 0 && NRES <= CGMEM_MAX_NRES && !SAT)>(a, SL, start, end, tid, wave, lane, start + (long long)NRES * TILE);
+            persist_publish(p, L.rows, ncp, L.flag, tid, 0u);
+        }
         // flavours with the pass-boundary prefetch: every later publish leaves the wave rows zeroed for the next pass
         if (NRES > 0 && p.nservice != 0 && (p.opts & PERSIST_OPT_PREFETCH) != 0) {
             for (int i = tid; i < WAVES * 2 * ncp; i += BLOCK) L.rows[i] = 0.0;

@@ -44,7 +44,7 @@ class Counters(C.Structure):
                 ("persist_resident_tiles", C.c_int32), ("elem_bytes", C.c_int32),
                 ("transport", C.c_int32), ("tenants", C.c_int32),
                 ("launch_grid", C.c_int32), ("launch_ray_workgroups", C.c_int32), ("launch_reducers", C.c_int32),
-                ("fixed_narrow", C.c_int32), ("algorithmic_bytes_total", C.c_double)]
+                ("fixed_narrow", C.c_int32), ("carried_flux", C.c_int32), ("algorithmic_bytes_total", C.c_double)]
 
 
 class MsgwError(RuntimeError):

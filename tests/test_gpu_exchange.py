@@ -214,9 +214,9 @@ def _rehearse_bench(extra, size=("--rays-per-gpu", "60000")):
 def test_bench_strong_scaling_rehearsal():
     """"also run at 1, 2, 4 GPUs with the same total N".  `--total-rays` divides one ray set over
     the ranks (the line then says "scaling": "strong"); with N > 1 and no --workload the bench runs config 4."""
-    d = _rehearse_bench(["--total-rays", "100001"], size=())
+    d = _rehearse_bench(["--total-rays", "100400"], size=())          # (the spectrum tiles 100 x 4 bins: multiples of 400)
     assert d["scaling"] == "strong" and d["n_gpus"] == 2
-    assert d["config"]["rays_total"] == 100001 and d["config"]["rays_per_gpu"] == 50000
+    assert d["config"]["rays_total"] == 100400 and d["config"]["rays_per_gpu"] == 50200
     assert d["config"]["workload"].startswith("config4") and d["dtype"] == "f64"
     assert d["config"]["launch_ray_workgroups"] > 0 and d["config"]["launch_workgroups"] > d["config"]["launch_ray_workgroups"]
     assert d["state_finite"] is True and d["value"] > 0

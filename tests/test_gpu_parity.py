@@ -547,3 +547,58 @@ def test_smallest_columns_vs_c_oracle(ngrid):
             os.environ.pop("MSGW_PERSIST", None) if old is None else os.environ.__setitem__("MSGW_PERSIST", old)
     with pytest.raises(_capi.MsgwError, match="ngrid >= 5"):
         _capi.Propagator(4, 100)
+
+
+def test_flux_carried_between_calls(monkeypatch):
+    """A persistent launch leaves the flux of its final state behind; the next launch takes it as F_0 instead of running
+    a deposit-only pre-pass -- as long as nothing has touched the state in between and the kernel flavour is the same.
+    Same results as with the pre-pass (to summation order), and every way of invalidating it is honoured."""
+    s, st = _random_case(200_003, 91, False, "uniform", True)
+    st[0] = st[0] * 1e-3
+    want = COracle(s).step(60.0, 9, st)
+
+    def run(carry):
+        monkeypatch.setenv("MSGW_CARRY", "1" if carry else "0")
+        p = make_prop(s, st)
+        flags = []
+        for k in (2, 3, 4):
+            p.step(60.0, k)
+            flags.append(p.counters()["carried_flux"])
+        out = gpu_state(p, st)
+        p.close()
+        return out, flags
+
+    a, fa = run(True)
+    b, fb = run(False)
+    assert fa == [0, 1, 1] and fb == [0, 0, 0]
+    check_state(a, want, 1e-10, 1e-11, "carried")
+    check_state(b, want, 1e-10, 1e-11, "pre-pass")
+    check_state(a, b, 1e-12, 1e-12, "carried vs pre-pass")
+    monkeypatch.setenv("MSGW_CARRY", "1")
+    p = make_prop(s, st)
+    p.step(60.0, 1)
+    p.step(60.0, 1)
+    assert p.counters()["carried_flux"] == 1
+    dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = st
+    p.upload_rays(dens, rr, drr, kk, ll, mm, dmm, phi, s.dkk, s.dll, s.rr_mm_area)       # a new state
+    p.step(60.0, 1)
+    assert p.counters()["carried_flux"] == 0
+    p.step(60.0, 1, _capi.RELAUNCH)                              # another kernel flavour
+    assert p.counters()["carried_flux"] == 0
+    p.step(60.0, 1, _capi.RELAUNCH)
+    assert p.counters()["carried_flux"] == 1
+    p.step(60.0, 1, _capi.FIXED_BACKGROUND)                      # the state advanced through another kernel
+    p.step(60.0, 1, _capi.RELAUNCH)
+    assert p.counters()["carried_flux"] == 0
+    p.set_config(s.bvf, s.phi0, s.kappa, s.saturate_online)      # the flux depends on the configuration
+    p.step(60.0, 1, _capi.RELAUNCH)
+    assert p.counters()["carried_flux"] == 0
+    p.close()
+    # and the whole sequence above against the oracle, so that a stale F_0 anywhere would show
+    p = make_prop(s, st)
+    p.step(60.0, 1); p.step(60.0, 1)
+    p.set_column(s.grid, s.grids, s.rhobar, s.pressure_gradient, uu, vv)
+    p.upload_rays(dens, rr, drr, kk, ll, mm, dmm, phi, s.dkk, s.dll, s.rr_mm_area)
+    p.step(60.0, 2); p.step(60.0, 3)
+    check_state(gpu_state(p, st), COracle(s).step(60.0, 5, st), 1e-10, 1e-11, "after a re-upload")
+    p.close()
