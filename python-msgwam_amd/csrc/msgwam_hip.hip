@@ -802,6 +802,7 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     if (const char *e = std::getenv("MSGW_PRIO")) pa.opts = std::atoi(e) ? PERSIST_OPT_PRIO : 0u;
     if (c->prefetch) pa.opts |= PERSIST_OPT_PREFETCH;
     { const char *e = std::getenv("MSGW_LEANPOLL"); if (!e || std::atoi(e)) pa.opts |= PERSIST_OPT_LEANPOLL; }
+    if (const char *e = std::getenv("MSGW_NAP")) pa.opts |= std::atoi(e) == 1 ? PERSIST_OPT_NAP1 : (std::atoi(e) == 8 ? PERSIST_OPT_NAP8 : 0u);
     if (c->balance && pl.nres > 0 && pl.nservice) {
         // MSGW_BALANCE=<abc> (diagnostic): priorities of a workgroup released on arrival / that had to wait / prefetched
         const int b = c->balance == 1 ? 202 : c->balance;

@@ -57,6 +57,7 @@ __device__ __forceinline__ void setprio_rt(unsigned int v)    // s_setprio takes
 constexpr unsigned int PERSIST_OPT_BALANCE = 4u;    // a workgroup that finds its pass released on arrival raises its wave priority (persist_stage)
 constexpr unsigned int PERSIST_OPT_PREFETCH = 2u;   // early poll + table prefetch at the pass boundary (persist_publish)
 constexpr unsigned int PERSIST_OPT_LEANPOLL = 8u;   // wait loops look at the status word / clock every 16th poll only
+constexpr unsigned int PERSIST_OPT_NAP1 = 1u << 12, PERSIST_OPT_NAP8 = 1u << 13;   // nap between two polls of a release: s_sleep 1 / 8 instead of 2
 constexpr int PERSIST_GROUPS = 32;       // most groups (= group sums added in the prologue)
 constexpr int PD_ROW = 64;               // (unused since the column workgroup does the sum over the ranks itself)
 constexpr int PD_LOCAL = 96;             // ready[PD_LOCAL]: several ranks: fluxes whose rank row is complete
@@ -357,7 +358,10 @@ __device__ __forceinline__ bool persist_wait_seen(const PersistArgsT<T> p, unsig
             const unsigned long long t0 = wall_clock64();
             unsigned int polls = 0;
             while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                __builtin_amdgcn_s_sleep(8);
+                // nap between two polls: s_sleep 2 (measured 8 / 4 / 2 / 1: config 3 33.40 / 33.35 / 33.13 / see DESIGN.md 6)
+                if (p.opts & PERSIST_OPT_NAP1) __builtin_amdgcn_s_sleep(1);        // (MSGW_NAP=1 | 8: diagnostic)
+                else if (p.opts & PERSIST_OPT_NAP8) __builtin_amdgcn_s_sleep(8);
+                else __builtin_amdgcn_s_sleep(2);
                 if ((p.opts & PERSIST_OPT_LEANPOLL) && (++polls & 15u) != 0u) continue;
                 if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                     wall_clock64() - t0 > p.timeout_ticks) {
