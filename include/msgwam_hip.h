@@ -207,6 +207,11 @@ int msgw_saturation(msgw_ctx *ctx, int64_t n, double dt, int direct,
                     const double *dkk, const double *dll, const double *rr_mm_area,
                     double *out);
 
+/* Test support (no reference counterpart): the float64 square root and the division by a constant d exactly as the ray
+ * kernels evaluate them (IEEE sqrt; Markstein's x / d for d >= 1; lib/libprop.py:383, :124, :694 are what they stand for), element by element on x [n] -> out_sqrt [n], out_div [n], so that the parity tests can hold
+ * them bit for bit to numpy's sqrt(x) and x / d over the whole exponent range. */
+int msgw_probe_arith(msgw_ctx *ctx, int64_t n, const double *x, double d, double *out_sqrt, double *out_div);
+
 /* Copy the evolving slots back (blocking). Any pointer may be NULL. */
 int msgw_download_rays(msgw_ctx *ctx, int64_t n, double *dens, double *rr, double *mm);
 int msgw_download_column(msgw_ctx *ctx, double *uu, double *vv);

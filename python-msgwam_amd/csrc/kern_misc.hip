@@ -65,6 +65,7 @@ const void *saturation_kernel() { return KPTR(k_saturation); }
 const void *flux_reduce1_kernel() { return KPTR(k_flux_reduce1); }
 const void *rho_slopes_kernel() { return KPTR(k_rho_slopes); }
 const void *xch_selftest_kernel() { return KPTR(k_xch_selftest); }
+const void *probe_arith_kernel() { return KPTR(k_probe_arith); }
 const void *convert_kernel_d2f() { return KPTR(k_convert<double, float>); }
 const void *convert_kernel_f2d() { return KPTR(k_convert<float, double>); }
 

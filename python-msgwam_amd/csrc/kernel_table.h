@@ -69,6 +69,7 @@ const void *saturation_kernel();
 const void *flux_reduce1_kernel();
 const void *rho_slopes_kernel();
 const void *xch_selftest_kernel();
+const void *probe_arith_kernel();                         // k_probe_arith
 
 // compile-time bool dispatch used by the look-up functions
 template <class F>

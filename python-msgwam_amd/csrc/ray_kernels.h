@@ -365,7 +365,10 @@ __device__ __forceinline__ T div_const(T x, T d, T c, int ok)
     const T r = fma(-d, q, x);
     const T q2 = fma(r, c, q);
     if constexpr (ANYNAN) return q2;
-    return (fabs(x) < real_inf<T>()) ? q2 : q;
+    // non-finite x: q2 is NaN (inf - inf) where x / d is +-inf.  v_div_fixup_f64 -- the last instruction of the IEEE
+    // division sequence -- puts that right in ONE instruction (inf / finite -> +-inf, NaN -> NaN, else the quotient with
+    // the sign of x / d) where a class test and two selects took three
+    return div_fixup_(q2, d, x);
 }
 template <typename T> __device__ __forceinline__ T third_rn() { return T(1) / T(3); }
 

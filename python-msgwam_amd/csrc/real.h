@@ -102,7 +102,14 @@ template <typename T> __device__ __forceinline__ T real_inf() { return std::nume
 // frequencies ~1e-3, densities 1e-15..1e20).
 __device__ __forceinline__ double div_(double x, double y) { return x / y; }
 __device__ __forceinline__ float div_(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
+// (Round 3 measured a 10-instruction float64 square root for 2^-767 <= x < inf -- hipcc's own chain without the scaling of
+// tiny arguments and the class test, bit for bit numpy's on 2e6 inputs -- behind one rarely-true test: 9 of ~102 VALU
+// instructions of a fixed-background ray-stage less, and the same 1.56 us per step at 1e5 rays and 33.4 at config 3:
+// those kernels wait on dependent results, they do not run out of issue slots.  Not kept.)
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+// v_div_fixup: the quotient q of x / d with the special cases of IEEE division put right (see div_const)
+__device__ __forceinline__ double div_fixup_(double q, double d, double x) { return __builtin_amdgcn_div_fixup(q, d, x); }
+__device__ __forceinline__ float div_fixup_(float q, float d, float x) { return __builtin_amdgcn_div_fixupf(q, d, x); }
 
 }   // namespace msgw

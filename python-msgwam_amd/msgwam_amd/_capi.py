@@ -30,6 +30,7 @@ EXPORTS = [
     "msgw_project_arrays", "msgw_saturation", "msgw_download_rays", "msgw_download_column",
     "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters", "msgw_set_relaunch", "msgw_upload_hprop", "msgw_download_hprop",
     "msgw_snapshot_create", "msgw_snapshot_download", "msgw_snapshot_destroy", "msgw_set_bvf_column", "msgw_download_extents",
+    "msgw_probe_arith",
 ]
 
 _dp = C.POINTER(C.c_double)
@@ -91,6 +92,7 @@ def load_library():
     lib.msgw_set_bvf_column.argtypes = [C.c_void_p, _dp]
     lib.msgw_download_extents.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp, _dp]
     lib.msgw_snapshot_destroy.argtypes = [C.c_void_p, C.c_void_p]
+    lib.msgw_probe_arith.argtypes = [C.c_void_p, C.c_int64, _dp, C.c_double, _dp, _dp]
     if lib.msgw_abi_version() != 3:
         raise MsgwError("libmsgwam_hip.so has an unexpected ABI version")
     _lib = lib
@@ -285,6 +287,13 @@ class Propagator:
     def snapshot_free(self, snap):
         if getattr(self, "ctx", None):
             self.lib.msgw_snapshot_destroy(self.ctx, snap[0])
+
+    def probe_arith(self, x, d):
+        """Test support: (sqrt(x), x / d) as the ray kernels evaluate them (include/msgwam_hip.h)."""
+        x = _c(x)
+        s, q = np.empty(len(x)), np.empty(len(x))
+        self._chk(self.lib.msgw_probe_arith(self.ctx, len(x), _p(x), float(d), _p(s), _p(q)), "msgw_probe_arith")
+        return s, q
 
     def sync(self):
         self._chk(self.lib.msgw_sync(self.ctx), "msgw_sync")

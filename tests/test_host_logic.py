@@ -172,3 +172,25 @@ def test_digest_without_xxhash_is_position_sensitive(monkeypatch):
     assert not lprop._slot_resident(a, key)
     e = np.zeros(0)
     assert lprop._slot_resident(e, lprop._slot_key(e))               # empty arrays digest too
+
+
+def test_committed_counter_table_matches_the_kernel_sources():
+    """bench.py's roofline reads HBM bytes and VALU instruction counts per kernel flavour from profiles/traffic.json
+    (rocprofv3 PMC passes).  Every entry carries the digest of csrc/ it was measured at; a kernel change without a new
+    profile run makes the bench line say `traffic_stale` -- and fails here, so that it cannot be committed unnoticed."""
+    import json
+    import os
+    import bench
+    table, err = bench.load_counter_table()
+    assert table is not None, err
+    digest = bench.kernel_src_digest()
+    keys = [k for k in table if not k.startswith("_")]
+    assert {"config3:f64:1000000:res4", "config3:f64:1000000:res0", "config2:f64:100000:res0:narrow",
+            "config5:f64:1250000:res4".replace("f64", "f32")} <= set(keys)
+    for k in keys:
+        e = table[k]
+        assert e.get("src_digest") == digest, (k, "profiles/traffic.json predates the current kernel sources: re-run "
+                                                  "tools/profile_all.sh + tools/make_counter_table.py")
+        assert os.path.exists(os.path.join(os.path.dirname(bench.__file__), e["source"]))
+        assert e.get("valu_wave_insts_per_ray_step", 0) > 0
+        assert ("bytes_per_ray_step" in e) != ("bytes_per_ray_launch" in e)
