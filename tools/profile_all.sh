@@ -8,8 +8,8 @@ tools/profile2.sh r03_config3_4e6 bench.py --workload config3 --rays-per-gpu 400
 tools/profile2.sh r03_config4_shard bench.py --workload config4 $B && \
 tools/profile2.sh r03_config5 bench.py --workload config5 $B && \
 MSGW_REGTILES=0 tools/profile2.sh r03_config5_streamed bench.py --workload config5 $B && \
-tools/profile2.sh r03_config2 bench.py --workload config2 --steps 1000 --warmup 100 --repeats 3 --no-cpu-baseline --kernel-events separate && \
-MSGW_FIXED_NARROW=0 tools/profile2.sh r03_config2_wide bench.py --workload config2 --steps 1000 --warmup 100 --repeats 3 --no-cpu-baseline --kernel-events separate && \
+tools/profile2.sh r03_config2 bench.py --workload config2 --steps 1000 --warmup 1000 --repeats 3 --no-cpu-baseline --kernel-events separate && \
+MSGW_FIXED_NARROW=0 tools/profile2.sh r03_config2_wide bench.py --workload config2 --steps 1000 --warmup 1000 --repeats 3 --no-cpu-baseline --kernel-events separate && \
 MSGW_PERSIST=0 tools/profile2.sh r03_chain bench.py --workload config3 $B && \
 tools/profile2.sh r03_hprop tools/run_variant.py hprop 1000000 30 && \
 tools/profile2.sh r03_nz tools/run_variant.py nz 1000000 30
