@@ -123,6 +123,10 @@ def cpu_baseline(wl, grid, uu, vv, budget_s=12.0):
             "vectorised_numpy_value": vec_rate, "c_port_value": c_rate}
 
 
+def coupled_workload(w):
+    return w["flags"] != "fixed"
+
+
 def kernel_src_digest():
     """Digest of the device code's sources: profiles/traffic.json entries carry the digest they were measured at, so a
     line can say when its committed counter figures predate a kernel change (`traffic_stale`)."""
@@ -177,6 +181,8 @@ def main():
     ap.add_argument("--total-rays", type=int, default=0,
                     help="strong scaling: this many rays in total, divided evenly over the N ranks (SURVEY 8d: the "
                          "same-total-N table of config 4)")
+    ap.add_argument("--no-exchange-check", action="store_true",
+                    help="N>1: skip the one-step comparison of the in-kernel exchange with the RCCL chain before timing")
     ap.add_argument("--no-streamed-leg", action="store_true",
                     help="skip the all-rays-streamed measurement (MSGW_REGTILES=0) behind roofline.hbm_streamed")
     ap.add_argument("--ngrid", type=int, default=101)
@@ -380,6 +386,69 @@ def main():
     ladder = [None, {"MSGW_XCH_TRANSPORT": "shm"}, {"MSGW_EXCHANGE": "0"}]
     if os.environ.get("MSGW_EXCHANGE_ONLY"):
         ladder = ladder[:2]                                    # no RCCL communicator to fall back on
+
+    def one_step_state(env):
+        """One RK3 step of this rank's shard through the transport `env` selects; (rays, column) or an ExchangeFailed."""
+        old = {k: os.environ.get(k) for k in (env or {})}
+        os.environ.update(env or {})
+        try:
+            n_total = args.total_rays or rays_per_gpu * world
+            lo, hi = shard_bounds(n_total, world, rank)
+            sp = gaussian_spectrum(n_total, grids, lprop.rhobar, alpha=W["alpha"], start=lo, stop=hi)
+            p = _capi.Propagator(args.ngrid, hi - lo, device=local_rank, dtype=W["dtype"])
+            err = None
+            try:
+                p.set_config(0.01, 0.0, 1.0, W["sat"])
+                p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, uu, vv)
+                p.upload_rays(sp["dens"], sp["rr"], sp["drr"], sp["kk"], sp["ll"], sp["mm"], sp["dmm"], sp["phi"],
+                              sp["dkk"], sp["dll"], sp["area"])
+                p.comm_init(fresh_uid(), rank, world)
+                tr = _capi.TRANSPORTS.get(p.counters().get("transport", 0))
+                p.step(DT, 1, flags)
+                rays, col = p.download_rays(), p.download_column()
+            except _capi.MsgwError as e:
+                err, rays, col, tr = str(e), None, None, None
+            try:
+                p.close()
+            except Exception:      # noqa: BLE001
+                pass
+            if dist is not None and all_flag(err is not None):
+                raise ExchangeFailed(err or "another rank reported a failure")
+            if err is not None:
+                raise ExchangeFailed(err)
+            return rays, col, tr
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    # Before any multi-rank timing: ONE step through the in-kernel exchange against the same step through the RCCL
+    # all-reduce chain, from the same state (ADVICE round 2: the device-resident transport has only ever run with rank
+    # processes sharing one GPU).  Same per-ray arithmetic, flux rows summed in a different order: 1e-12 is generous.  A
+    # mismatch takes the in-kernel exchange out of the ladder; the line says so either way (`config.exchange_check`).
+    exchange_check = None
+    if (world > 1 or args.force_collective) and coupled_workload(W) and not os.environ.get("MSGW_EXCHANGE_ONLY") \
+            and os.environ.get("MSGW_EXCHANGE", "1") != "0" and not args.no_exchange_check:
+        try:
+            (r1, c1_, t1), (r2, c2_, t2) = one_step_state(None), one_step_state({"MSGW_EXCHANGE": "0"})
+            scale = max(float(np.max(np.abs(c2_[0]))), float(np.max(np.abs(c2_[1]))), 1e-300)
+            d_col = max(float(np.max(np.abs(c1_[0] - c2_[0]))), float(np.max(np.abs(c1_[1] - c2_[1])))) / scale
+            d_ray = max(float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) for a, b in zip(r1[1:], r2[1:]))
+            tol = 1e-12 if W["dtype"] == "f64" else 1e-5
+            bad = not (d_col <= tol and d_ray <= tol)
+            if dist is not None:
+                bad = all_flag(bad)
+            exchange_check = {"transports": [t1, t2], "column_max_diff_over_scale": d_col, "ray_max_rel_diff": d_ray,
+                              "tolerance": tol, "ok": not bad}
+            if bad:
+                ladder = ladder[2:]
+                if rank == 0:
+                    print("bench.py: the in-kernel exchange disagrees with the RCCL chain; timing the RCCL chain", file=sys.stderr, flush=True)
+        except ExchangeFailed as e:
+            exchange_check = {"ok": False, "error": str(e)}
+            ladder = ladder[2:]
     m = None
     for env in ladder:
         if env:
@@ -561,6 +630,7 @@ def main():
                        "ngrid": args.ngrid,
                        "dt": DT, "parallelism": par, "transport": transport,
                        **({"transport_fallbacks": fell_back} if fell_back else {}),
+                       **({"exchange_check": exchange_check} if exchange_check is not None else {}),
                        "graph_steps": c1["graph_steps"], "persist_steps": persist_steps,
                        "launch_workgroups": c1.get("launch_grid", 0),
                        "launch_ray_workgroups": c1.get("launch_ray_workgroups", 0),

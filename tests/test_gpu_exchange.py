@@ -255,3 +255,22 @@ def test_bench_multi_rank_launch_rehearsal(tmp_path):
     assert d["config"]["rays_total"] == 120000 and d["state_finite"] is True
     assert "inside the persistent kernel" in d["config"]["parallelism"]
     assert d["roofline"]["kernel"] == "k_rk3_persist" and d["value"] > 0
+
+
+def test_bench_checks_the_exchange_against_the_rccl_chain_before_timing():
+    """bench.py, whenever it times a multi-rank path with an RCCL communicator at hand: ONE step through the in-kernel
+    exchange against the same step through the all-reduce chain first (the device-resident transport has never run on
+    distinct GPUs: the first 8-GPU run must not report throughput of a wrong exchange).  Rehearsed with a 1-rank
+    communicator."""
+    import json
+    root = os.path.join(HERE, "..")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-collective", "--steps", "4", "--warmup", "2",
+           "--rays-per-gpu", "100000", "--no-cpu-baseline", "--no-size-sweep", "--no-streamed-leg"]
+    r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    d = json.loads([l for l in out.splitlines() if l.startswith("{") and '"metric"' in l][-1])
+    chk = d["config"]["exchange_check"]
+    assert chk["ok"] is True and chk["transports"] == ["device_ipc", "rccl"], chk
+    assert chk["column_max_diff_over_scale"] <= 1e-12 and chk["ray_max_rel_diff"] <= 1e-12
+    assert d["config"]["transport"] == "device_ipc" and d["config"]["persist_steps"] == 4
