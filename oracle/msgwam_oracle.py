@@ -261,8 +261,6 @@ def rhs(setup, dt, state, loop=False, fixed_background=False, return_flux=False,
     """
     dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = state
     ncol = np.ndim(setup.bvf) != 0                       # EXTENSION: N as a column on grids (see bvf_at)
-    if ncol and setup.hprop:
-        raise NotImplementedError("the N(z) column extension is defined for HPROP_GLOBAL = False only")
     bvf = bvf_at(setup, rr)                              # scalar bvf: the scalar itself
     cgr_up = cg_rr(kk, ll, mm, phi, bvf_at(setup, rr + .5 * drr))     # :635 (rr unused there: scalar bvf)
     cgr_down = cg_rr(kk, ll, mm, phi, bvf_at(setup, rr - .5 * drr))   # :636

@@ -1,11 +1,9 @@
-// The float64-only kernels: standalone column kernel, HPROP_GLOBAL = True stage kernel, projections and
+// The float64-only kernels: standalone column kernel, projections and
 // saturation on caller arrays, first-level flux reduction, exchange self-test, float32 <-> float64 conversion.
 #include <type_traits>
 #include "kernel_table.h"
 #include "column_kernels.h"
-#include "hprop_kernels.h"
 #include "misc_kernels.h"
-#include "nz_kernels.h"
 
 namespace msgw {
 
@@ -32,31 +30,8 @@ const void *column_kernel(int stage, int mode)
     }
     return nullptr;
 }
-template <int RPT>
-static const void *hprop_rpt(int stage, bool sat)
-{
-    switch (stage) {
-    case 0: return sat ? KPTR(k_ray_stage_hprop<0, true, RPT>) : KPTR(k_ray_stage_hprop<0, false, RPT>);
-    case 1: return sat ? KPTR(k_ray_stage_hprop<1, true, RPT>) : KPTR(k_ray_stage_hprop<1, false, RPT>);
-    case 2: return sat ? KPTR(k_ray_stage_hprop<2, true, RPT>) : KPTR(k_ray_stage_hprop<2, false, RPT>);
-    case 3: return sat ? KPTR(k_ray_stage_hprop<3, true, RPT>) : KPTR(k_ray_stage_hprop<3, false, RPT>);
-    }
-    return nullptr;
-}
-const void *hprop_kernel(int stage, bool sat, int rpt) { return rpt == 1 ? hprop_rpt<1>(stage, sat) : hprop_rpt<2>(stage, sat); }
-template <int RPT>
-static const void *nz_rpt(int stage, bool sat)
-{
-    switch (stage) {
-    case 0: return sat ? KPTR(k_ray_stage_nz<0, true, RPT>) : KPTR(k_ray_stage_nz<0, false, RPT>);
-    case 1: return sat ? KPTR(k_ray_stage_nz<1, true, RPT>) : KPTR(k_ray_stage_nz<1, false, RPT>);
-    case 2: return sat ? KPTR(k_ray_stage_nz<2, true, RPT>) : KPTR(k_ray_stage_nz<2, false, RPT>);
-    case 3: return sat ? KPTR(k_ray_stage_nz<3, true, RPT>) : KPTR(k_ray_stage_nz<3, false, RPT>);
-    }
-    return nullptr;
-}
-const void *nz_kernel(int stage, bool sat, int rpt) { return rpt == 1 ? nz_rpt<1>(stage, sat) : nz_rpt<2>(stage, sat); }
-const void *nz_prepare_kernel() { return KPTR(k_nz_prepare); }
+template <> const void *nz_prepare_kernel<double>() { return KPTR(k_nz_prepare<double>); }
+template <> const void *nz_prepare_kernel<float>() { return KPTR(k_nz_prepare<float>); }
 const void *project_arrays_kernel(int np)
 {
     return np == 2 ? KPTR(k_project<double, 2, true, true>) : KPTR(k_project<double, 1, true, true>);

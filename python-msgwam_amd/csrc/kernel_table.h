@@ -59,11 +59,20 @@ inline const void *persist_kernel(bool sat, bool fvec, bool direct, int nres, bo
                     : persist_kernel_impl<T, 0>(sat, fvec, direct, relaunch);
 }
 
+// k_ray_stage_chain<T, STAGE, SAT, HPROP, NZ> (HPROP_GLOBAL = True and / or the N(z) column extension); one explicit
+// specialisation per (T, HPROP, NZ) lives in kern_chain.hip
+template <typename T, bool HPROP, bool NZ>
+const void *chain_kernel_impl(int stage, bool sat);
+template <typename T>
+inline const void *chain_kernel(int stage, bool sat, bool hprop, bool nz)
+{
+    return hprop ? (nz ? chain_kernel_impl<T, true, true>(stage, sat) : chain_kernel_impl<T, true, false>(stage, sat))
+                 : (nz ? chain_kernel_impl<T, false, true>(stage, sat) : nullptr);
+}
+template <typename T> const void *nz_prepare_kernel();                               // k_nz_prepare<T>
+
 // float64-only kernels (kern_misc.hip)
 const void *column_kernel(int stage, int mode);          // k_column<STAGE, MODE>
-const void *hprop_kernel(int stage, bool sat, int rpt = 2);   // k_ray_stage_hprop<STAGE, SAT, RPT>
-const void *nz_kernel(int stage, bool sat, int rpt = 2);      // k_ray_stage_nz<STAGE, SAT, RPT> (N(z) column extension)
-const void *nz_prepare_kernel();
 const void *project_arrays_kernel(int np);               // k_project<double, NP, true, true>
 const void *saturation_kernel();
 const void *flux_reduce1_kernel();

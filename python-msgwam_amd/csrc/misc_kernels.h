@@ -82,12 +82,13 @@ __global__ void k_rho_slopes(int nc, const double *grids, const double *rhobar, 
 
 
 // dkk*dll (:137, :599) and rr_mm_area (:594) per ray, once per upload
-__global__ void k_nz_prepare(long long n, const double *dkk, const double *dll, const double *area, double *dkdl, double *area_out)
+template <typename T>
+__global__ void k_nz_prepare(long long n, const double *dkk, const double *dll, const double *area, T *dkdl, T *area_out)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    dkdl[i] = dkk[i] * dll[i];
-    area_out[i] = area[i];
+    dkdl[i] = (T)(dkk[i] * dll[i]);
+    area_out[i] = (T)area[i];
 }
 
 

@@ -26,8 +26,7 @@
 
 #include "kernel_table.h"
 #include "column_kernels.h"
-#include "hprop_kernels.h"
-#include "nz_kernels.h"
+#include "chain_kernels.h"
 #include "persist_kernel.h"
 #include "ray_kernels.h"
 
@@ -132,13 +131,14 @@ struct msgw_ctx {
     // HPROP_GLOBAL = True (horizontal propagation): lam, phi and their RK registers, registers of kk, ll
     int hprop = 0;
     bool have_hprop = false;
-    double *lam = nullptr, *phi = nullptr, *q_lam = nullptr, *q_phi = nullptr, *q_kk = nullptr, *q_ll = nullptr;
+    void *lam = nullptr, *phi = nullptr, *q_lam = nullptr, *q_phi = nullptr, *q_kk = nullptr, *q_ll = nullptr;   // (ray type)
     bool fvec = false;
     double f_uni = 0;
     // EXTENSION: N as a column on grids (msgw_set_bvf_column): drr, dmm evolve too; a per-stage kernel of its own
     int nz = 0;
     bool have_nz = false;            // dkdl / area of the resident rays are in place
-    double *bvfcol = nullptr, *nz_q_drr = nullptr, *nz_q_dmm = nullptr, *nz_dkdl = nullptr, *nz_area = nullptr;
+    double *bvfcol = nullptr;        // [ng-1] N on grids (float64 in both modes, like the rest of the column)
+    void *nz_q_drr = nullptr, *nz_q_dmm = nullptr, *nz_dkdl = nullptr, *nz_area = nullptr, *nz_drr0 = nullptr;   // (ray type)
 
     // column
     double *colbuf = nullptr;
@@ -173,7 +173,6 @@ struct msgw_ctx {
     int service = 1;                 // reducer workgroups beside the workers (MSGW_SERVICE=0: last arriver reduces)
     int balance = 1;                 // laggard workgroups of a CU raise their wave priority (MSGW_BALANCE=0 | 1)
     int prefetch = 1;                // early poll + table prefetch at the pass boundary of the resident-tile flavours (MSGW_PREFETCH=0 | 1)
-    int chain_rpt = 2;                   // rays per lane of the HPROP / N(z) stage kernels (MSGW_CHAIN_RPT=1 | 2; 1 measured no faster)
     int fixed_narrow_force = -1;         // MSGW_FIXED_NARROW=0 | 1 (diagnostic), read when the context is created
     int64_t fixed_narrow_max = 400000;   // fixed background: ray counts up to this run one ray per lane (launch_fixed)
     int regtiles = 4;                // most register-resident tiles per workgroup in the persistent kernel (MSGW_REGTILES=0 | 2 | 4)
@@ -993,40 +992,41 @@ int ready(msgw_ctx *c)
     if (!c->have_rays) return fail(c, MSGW_ERR_ARG, "msgw_upload_rays has not been called");
     if (c->hprop && !c->have_hprop) return fail(c, MSGW_ERR_ARG, "HPROP is on: msgw_upload_hprop (lam, phi) has not been called");
     if (c->nz && !c->have_nz) return fail(c, MSGW_ERR_ARG, "an N(z) column is set: call msgw_upload_rays after msgw_set_bvf_column");
-    if (c->nz && c->hprop) return fail(c, MSGW_ERR_UNSUP, "the N(z) column extension is defined for HPROP_GLOBAL = False only");
     return MSGW_OK;
 }
 
-// ---- HPROP_GLOBAL = True: its own per-stage kernel + the standalone column kernel (float64 only)
-size_t hprop_lds_bytes(const msgw_ctx *c) { return stage_lds_bytes(c) + sizeof(double) * (4 * (size_t)(c->ng - 1) + 2); }
-
-HpropArgs make_hprop_args(msgw_ctx *c, double dt, unsigned flags)
+// ---- HPROP_GLOBAL = True and / or the N(z) column extension: the general per-stage kernel (chain_kernels.h) + the
+// standalone column kernel.  Online saturation is a compile-time variant; the driver's direct saturation and the
+// relaunch extension are run-time branches of the stage-2 kernel.
+template <typename T>
+ChainArgsT<T> make_chain_args(msgw_ctx *c, double dt, unsigned flags)
 {
-    HpropArgs h{};
-    h.s = make_stage_args<double>(c, dt, flags);
-    auto d = [](void *v) { return static_cast<double *>(v); };
-    h.lam = c->lam; h.phi = c->phi; h.kk = d(c->kk); h.ll = d(c->ll);
-    h.q_lam = c->q_lam; h.q_phi = c->q_phi; h.q_kk = c->q_kk; h.q_ll = c->q_ll;
+    ChainArgsT<T> h{};
+    h.s = make_stage_args<T>(c, dt, flags);
+    auto t = [](void *v) { return static_cast<T *>(v); };
+    h.lam = t(c->lam); h.phi = t(c->phi); h.kk = t(c->kk); h.ll = t(c->ll);
+    h.q_lam = t(c->q_lam); h.q_phi = t(c->q_phi); h.q_kk = t(c->q_kk); h.q_ll = t(c->q_ll);
     h.uu = c->uu; h.vv = c->vv;
     const double rot = 7.2921e-5;                                  // ROT_EARTH  (lib/libprop.py:4)
-    h.rad_earth = 6378e3;                                          // RAD_EARTH  (lib/libprop.py:3)
-    h.two_rot = 2 * rot;
-    h.df2c = 8 * (rot * rot);                                      // 8 * ROT_EARTH**2 (:489)
+    h.rad_earth = (T)6378e3;                                       // RAD_EARTH  (lib/libprop.py:3)
+    h.two_rot = (T)(2 * rot);
+    h.df2c = (T)(8 * (rot * rot));                                 // 8 * ROT_EARTH**2 (:489)
+    h.drr = t(c->drr); h.dmm = t(c->dmm);
+    h.q_drr = t(c->nz_q_drr); h.q_dmm = t(c->nz_q_dmm); h.drr0 = t(c->nz_drr0);
+    h.dkdl = t(c->nz_dkdl); h.area = t(c->nz_area); h.bvf = c->bvfcol;
+    h.direct = (flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK)) ? 1 : 0;
     return h;
 }
 
-// The HPROP and N(z) stage kernels also exist with ONE ray per lane (MSGW_CHAIN_RPT=1): ~half the registers, four or five
-// wavefronts per SIMD instead of two.  Measured at 1e6 rays: HPROP 144.3 vs 146.2, N(z) 124.4 vs 127.8, N(z) + saturation
-// 143.8 vs 138.9 us per step -- no gain, i.e. these kernels are not latency-bound: they stream 170-190 B per ray and
-// stage at ~85 % of the device's copy rate.  Two rays per lane (16-byte accesses) stay the default.
-int launch_hprop_stage(msgw_ctx *c, int stage, HpropArgs h)
+template <typename T>
+int launch_chain_stage(msgw_ctx *c, int stage, const ChainArgsT<T> &h)
 {
-    if (c->chain_rpt == 1) h.s.tiles_per_block *= 2;           // tiles of 256 rays
-    return launch_struct(c, hprop_kernel(stage, c->sat_online != 0, c->chain_rpt), c->blocks, BLOCK, hprop_lds_bytes(c), h);
+    return launch_struct(c, chain_kernel<T>(stage, c->sat_online != 0, c->hprop != 0, c->nz != 0), c->blocks, BLOCK,
+                         chain_lds_bytes<T>(c->ng, c->hprop != 0, c->nz != 0), h);
 }
 
-// The stage kernels of the HPROP / N(z) chains reduce their flux rows inside the launch (flush_rows_group: one row in
-// c->flux) when a thread of the last reducer can own a column entry; the column kernel then only updates.
+// The stage kernels of this chain reduce their flux rows inside the launch (flush_rows_group: one row in c->flux) when a
+// thread of the last reducer can own a column entry; the column kernel then only updates.
 bool chain_group_reduce(const msgw_ctx *c)
 {
     static const bool off = [] { const char *e = std::getenv("MSGW_CHAIN_GROUPRED"); return e && std::atoi(e) == 0; }();
@@ -1039,46 +1039,29 @@ int column_from_row(msgw_ctx *c, int stage, const ColArgs &a)
     return launch_column(c, stage, COL_UPDATE, a);
 }
 
-int enqueue_steps_hprop(msgw_ctx *c, double dt, unsigned flags, int count)
+template <typename T>
+int enqueue_steps_chain(msgw_ctx *c, double dt, unsigned flags, int count)
 {
-    HpropArgs h = make_hprop_args(c, dt, flags);
+    ChainArgsT<T> h = make_chain_args<T>(c, dt, flags);
     h.group_reduce = chain_group_reduce(c) ? 1 : 0;
     const ColArgs ca = make_col_args(c, dt, flags);
     for (int step = 0; step < count; ++step)
         for (int s = 0; s < 3; ++s) {
-            if (int rc = launch_hprop_stage(c, s, h)) return rc;
+            if (int rc = launch_chain_stage<T>(c, s, h)) return rc;
             if (int rc = h.group_reduce ? column_from_row(c, s, ca) : column_stage(c, s, ca)) return rc;
         }
     return MSGW_OK;
 }
 
-// ---- N(z) column extension: its own per-stage kernel + the standalone column kernel (float64 only)
-NzArgs make_nz_args(msgw_ctx *c, double dt, unsigned flags)
+// SURVEY 8d accounting, words per ray-step of this chain = 3 L + 7 E: every stage reads L per-ray arrays (dens, rr, kk,
+// ll, mm; lam, phi or the per-ray f; drr and vol, or drr, dmm and dkk*dll with an N(z) column; the phase-volume factor
+// with online saturation) and writes the E evolving slots; their RK registers are written by stages 0, 1 and read by
+// stages 1, 2.  HPROP: 69, N(z): 55, N(z) + online saturation: 65, everything at once: 111.
+double chain_words_per_step(const msgw_ctx *c)
 {
-    NzArgs h{};
-    h.s = make_stage_args<double>(c, dt, flags);
-    h.drr = static_cast<double *>(c->drr); h.dmm = static_cast<double *>(c->dmm);
-    h.q_drr = c->nz_q_drr; h.q_dmm = c->nz_q_dmm; h.dkdl = c->nz_dkdl; h.area = c->nz_area; h.bvf = c->bvfcol;
-    return h;
-}
-
-int launch_nz_stage(msgw_ctx *c, int stage, NzArgs h)
-{
-    if (c->chain_rpt == 1) h.s.tiles_per_block *= 2;           // tiles of 256 rays
-    return launch_struct(c, nz_kernel(stage, c->sat_online != 0, c->chain_rpt), c->blocks, BLOCK, hprop_lds_bytes(c), h);
-}
-
-int enqueue_steps_nz(msgw_ctx *c, double dt, unsigned flags, int count)
-{
-    NzArgs h = make_nz_args(c, dt, flags);
-    h.group_reduce = chain_group_reduce(c) ? 1 : 0;
-    const ColArgs ca = make_col_args(c, dt, flags);
-    for (int step = 0; step < count; ++step)
-        for (int s = 0; s < 3; ++s) {
-            if (int rc = launch_nz_stage(c, s, h)) return rc;
-            if (int rc = h.group_reduce ? column_from_row(c, s, ca) : column_stage(c, s, ca)) return rc;
-        }
-    return MSGW_OK;
+    const int E = 2 + (c->sat_online ? 1 : 0) + (c->hprop ? 4 : 0) + (c->nz ? 2 : 0);
+    const int L = 5 + (c->hprop ? 2 : 1) + (c->nz ? 3 : 2) + (c->sat_online ? 1 : 0);
+    return 3.0 * L + 7.0 * E;
 }
 
 // float32 state <-> the float64 arrays of the C ABI: staged through a float64 device buffer and converted there
@@ -1308,7 +1291,6 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_FIXED_NARROW")) c->fixed_narrow_force = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_CARRY")) c->carry = std::atoi(e) ? 1 : 0;
-    if (const char *e = std::getenv("MSGW_CHAIN_RPT")) c->chain_rpt = std::atoi(e) == 1 ? 1 : 2;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_BALANCE")) c->balance = std::atoi(e);
     if (const char *e = std::getenv("MSGW_PREFETCH")) c->prefetch = std::atoi(e) ? 1 : 0;
@@ -1366,15 +1348,13 @@ int msgw_set_config(msgw_ctx *c, double bvf, double f0, double kappa, int satura
     if (!c) return MSGW_ERR_ARG;
     c->carry_key = 0;                                          // (the flux of the resident state depends on bvf and f)
     HIPCHK(c, hipSetDevice(c->device));
-    if (hprop && c->f32)
-        return fail(c, MSGW_ERR_UNSUP, "HPROP_GLOBAL = True is float64 only (create the context without MSGW_DTYPE_F32)");
     if (hprop && !c->lam) {                                    // the six extra ray arrays of the spherical branch
         const size_t padded = (((size_t)c->cap + c->tile - 1) / c->tile + 1) * c->tile;
-        double **hp[] = {&c->lam, &c->phi, &c->q_lam, &c->q_phi, &c->q_kk, &c->q_ll};
-        for (double **p : hp) {
-            HIPCHK(c, hipMalloc(p, padded * sizeof(double)));
+        void **hp[] = {&c->lam, &c->phi, &c->q_lam, &c->q_phi, &c->q_kk, &c->q_ll};
+        for (void **p : hp) {
+            HIPCHK(c, hipMalloc(p, padded * c->esz));
             c->ray_bufs.push_back(*p);
-            HIPCHK(c, hipMemsetAsync(*p, 0, padded * sizeof(double), c->stream));
+            HIPCHK(c, hipMemsetAsync(*p, 0, padded * c->esz, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -1471,9 +1451,12 @@ int msgw_upload_rays(msgw_ctx *c, int64_t n, const double *dens, const double *r
     if (rc) return rc;
     c->have_nz = false;
     if (c->nz) {                                               // N(z) column: dkk*dll and rr_mm_area stay on the device
-        if (int rc4 = launch_list(c, nz_prepare_kernel(), pg, 256, (long long)n, (const double *)s_dkk, (const double *)s_dll,
-                                  (const double *)s_area, c->nz_dkdl, c->nz_area))
-            return rc4;
+        const int rc4 = c->f32
+            ? launch_list(c, nz_prepare_kernel<float>(), pg, 256, (long long)n, (const double *)s_dkk, (const double *)s_dll,
+                          (const double *)s_area, static_cast<float *>(c->nz_dkdl), static_cast<float *>(c->nz_area))
+            : launch_list(c, nz_prepare_kernel<double>(), pg, 256, (long long)n, (const double *)s_dkk, (const double *)s_dll,
+                          (const double *)s_area, static_cast<double *>(c->nz_dkdl), static_cast<double *>(c->nz_area));
+        if (rc4) return rc4;
         c->have_nz = true;
     }
     // inert padding up to a whole tile (finite, never deposited: validity is index < n)
@@ -1508,9 +1491,10 @@ int msgw_upload_hprop(msgw_ctx *c, int64_t n, const double *lam, const double *p
     if (!c->hprop || !c->lam) return fail(c, MSGW_ERR_ARG, "HPROP is off (msgw_set_config(..., hprop = 1) first)");
     if (!c->have_rays || n != c->n) return fail(c, MSGW_ERR_ARG, "call msgw_upload_rays first, with the same n");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t B = (size_t)n * sizeof(double);
-    HIPCHK(c, hipMemcpyAsync(c->lam, lam, B, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->phi, phi, B, hipMemcpyHostToDevice, c->stream));
+    Staging st;
+    if (c->f32) HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)n * 2));
+    if (int rc = upload_array(c, c->lam, lam, n, st.p)) return rc;
+    if (int rc = upload_array(c, c->phi, phi, n, st.p ? st.p + n : nullptr)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_hprop = true;
     return MSGW_OK;
@@ -1521,12 +1505,14 @@ int msgw_download_hprop(msgw_ctx *c, int64_t n, int tendencies, double *lam, dou
     if (!c) return MSGW_ERR_ARG;
     if (!c->hprop || !c->have_hprop || n != c->n) return fail(c, MSGW_ERR_ARG, "no HPROP state of that size on the device");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t B = (size_t)n * sizeof(double);
+    if (int rc = check_status(c)) return rc;
     const void *src[4] = {tendencies ? c->q_lam : c->lam, tendencies ? c->q_phi : c->phi,
                           tendencies ? (const void *)c->q_kk : c->kk, tendencies ? (const void *)c->q_ll : c->ll};
     double *dst[4] = {lam, phi, kk, ll};
+    Staging st;
+    if (c->f32) HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)n * 4));
     for (int i = 0; i < 4; ++i)
-        if (dst[i]) HIPCHK(c, hipMemcpyAsync(dst[i], src[i], B, hipMemcpyDeviceToHost, c->stream));
+        if (dst[i]) if (int rc = download_array(c, dst[i], src[i], n, st.p ? st.p + (size_t)i * n : nullptr)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSGW_OK;
 }
@@ -1540,25 +1526,25 @@ int msgw_set_bvf_column(msgw_ctx *c, const double *bvf)
         c->nz = 0;
         return MSGW_OK;
     }
-    if (c->f32) return fail(c, MSGW_ERR_UNSUP, "the N(z) column extension is float64 only");
     const size_t nc = (size_t)c->ng - 1;
     if (!c->bvfcol) {
         // allocate into locals and commit only when everything is there: a failed call leaves the context as it was
         const size_t padded = (((size_t)c->cap + c->tile - 1) / c->tile + 1) * c->tile;
-        double *col = nullptr, *ray[4] = {nullptr, nullptr, nullptr, nullptr};
+        double *col = nullptr;
+        void *ray[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         bool ok = hipMalloc(&col, nc * sizeof(double)) == hipSuccess;
-        for (int i = 0; i < 4 && ok; ++i)
-            ok = hipMalloc(&ray[i], padded * sizeof(double)) == hipSuccess &&
-                 hipMemsetAsync(ray[i], 0, padded * sizeof(double), c->stream) == hipSuccess;
+        for (int i = 0; i < 5 && ok; ++i)
+            ok = hipMalloc(&ray[i], padded * c->esz) == hipSuccess &&
+                 hipMemsetAsync(ray[i], 0, padded * c->esz, c->stream) == hipSuccess;
         if (!ok) {
             (void)hipStreamSynchronize(c->stream);
-            for (double *p : ray) if (p) (void)hipFree(p);
+            for (void *p : ray) if (p) (void)hipFree(p);
             if (col) (void)hipFree(col);
             (void)hipGetLastError();
             return fail(c, MSGW_ERR_HIP, "hipMalloc of the N(z) column buffers failed");
         }
-        c->nz_q_drr = ray[0]; c->nz_q_dmm = ray[1]; c->nz_dkdl = ray[2]; c->nz_area = ray[3];
-        for (double *p : ray) c->ray_bufs.push_back(p);
+        c->nz_q_drr = ray[0]; c->nz_q_dmm = ray[1]; c->nz_dkdl = ray[2]; c->nz_area = ray[3]; c->nz_drr0 = ray[4];
+        for (void *p : ray) c->ray_bufs.push_back(p);
         c->bvfcol = col;
         c->ray_bufs.push_back(col);
     }
@@ -1630,28 +1616,14 @@ int msgw_step(msgw_ctx *c, double dt, int nsteps, unsigned flags)
     const unsigned gflags = flags & ~(MSGW_NO_GRAPH | MSGW_TIME_KERNELS);
     if (time_kernels) c->kev_used = 0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (c->hprop) {                                            // HPROP_GLOBAL = True: its own per-stage chain
-        if (flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK | MSGW_RELAUNCH))
-            return fail(c, MSGW_ERR_UNSUP, "the fused direct saturation and the relaunch extension are not "
-                        "available with HPROP on (use msgw_saturation on downloaded arrays)");
+    if (c->hprop || c->nz) {                                   // HPROP_GLOBAL = True / N(z) column: the general per-stage chain
         c->cnt.persist_steps = 0;
         c->carry_key = 0;
-        if (int rc = enqueue_steps_hprop(c, dt, gflags, nsteps)) return rc;
+        if (int rc = c->f32 ? enqueue_steps_chain<float>(c, dt, gflags, nsteps) : enqueue_steps_chain<double>(c, dt, gflags, nsteps))
+            return rc;
         HIPCHK(c, hipEventRecord(c->ev1, c->stream));
         c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
-        c->cnt.algorithmic_bytes_total += 71.0 * 8.0 * (double)c->n * nsteps;
-        return MSGW_OK;
-    }
-    if (c->nz) {                                               // N(z) column extension: its own per-stage chain
-        if (flags & (MSGW_DIRECT_SAT | MSGW_DIRECT_SAT_QUIRK | MSGW_RELAUNCH))
-            return fail(c, MSGW_ERR_UNSUP, "the fused direct saturation and the relaunch extension are not "
-                        "available with an N(z) column");
-        c->cnt.persist_steps = 0;
-        c->carry_key = 0;
-        if (int rc = enqueue_steps_nz(c, dt, gflags, nsteps)) return rc;
-        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-        c->cnt.ray_steps_total += c->n * (int64_t)nsteps;
-        c->cnt.algorithmic_bytes_total += 63.0 * 8.0 * (double)c->n * nsteps;
+        c->cnt.algorithmic_bytes_total += chain_words_per_step(c) * (double)c->esz * (double)c->n * nsteps;
         return MSGW_OK;
     }
     if (int rc = c->f32 ? step_impl<float>(c, dt, nsteps, gflags, eager, time_kernels)
@@ -1682,11 +1654,10 @@ int msgw_rhs(msgw_ctx *c, double dt, unsigned flags, double *st_dens, double *st
     if (int rc = ready(c)) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     if (int rc = check_status(c)) return rc;
-    if (c->hprop) {
-        const HpropArgs h = make_hprop_args(c, dt, flags);
-        if (int rc = launch_hprop_stage(c, 3, h)) return rc;
-    } else if (c->nz) {
-        if (int rc = launch_nz_stage(c, 3, make_nz_args(c, dt, flags))) return rc;
+    if (c->hprop || c->nz) {
+        if (int rc = c->f32 ? launch_chain_stage<float>(c, 3, make_chain_args<float>(c, dt, flags))
+                            : launch_chain_stage<double>(c, 3, make_chain_args<double>(c, dt, flags)))
+            return rc;
     } else if (c->f32) {
         if (int rc = launch_probe<float>(c, make_stage_args<float>(c, dt, flags), c->sat_online != 0, true)) return rc;
     } else {
@@ -1866,13 +1837,13 @@ int msgw_snapshot_create(msgw_ctx *c, msgw_snapshot **out)
     *out = nullptr;
     if (!c->have_rays || !c->have_column) return fail(c, MSGW_ERR_ARG, "nothing resident to snapshot");
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t ray = (size_t)c->n * c->esz, dbl = (size_t)c->n * sizeof(double);
+    const size_t ray = (size_t)c->n * c->esz;
     const size_t col = (size_t)(c->ng - 1) * sizeof(double);
     const bool hp = c->hprop && c->have_hprop, nz = c->nz && c->have_nz;
     msgw_snapshot *s = new msgw_snapshot();
     const void *src[MSGW_SLOT_COUNT] = {c->dens, c->rr, c->mm, c->uu, c->vv, hp ? c->lam : nullptr, hp ? c->phi : nullptr,
                                         hp ? c->kk : nullptr, hp ? c->ll : nullptr, nz ? c->drr : nullptr, nz ? c->dmm : nullptr};
-    const size_t len[MSGW_SLOT_COUNT] = {ray, ray, ray, col, col, dbl, dbl, ray, ray, ray, ray};
+    const size_t len[MSGW_SLOT_COUNT] = {ray, ray, ray, col, col, ray, ray, ray, ray, ray, ray};
     size_t bytes = 0;
     for (int k = 0; k < MSGW_SLOT_COUNT; ++k)
         if (src[k]) { s->off[k] = bytes; s->len[k] = len[k]; s->ray_typed[k] = len[k] == ray && k != MSGW_SLOT_UU && k != MSGW_SLOT_VV; bytes += (len[k] + 255) / 256 * 256; }

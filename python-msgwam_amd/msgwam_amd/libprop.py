@@ -13,9 +13,9 @@ setters; `omega`; and the hot-path entry points `RK3`, `rhs_default`,
 fallback for those four: without the HIP library or a GPU they raise.
 
 Scope and deliberate differences (also in DESIGN.md):
-  * `model_config['bvf']` is the reference's scalar or (EXTENSION) an array on `grids`; the array
-    form works with `HPROP_GLOBAL = False` only.  Both `HPROP_GLOBAL` branches run on the GPU: False (the driver's,
-    raytracer.py:38) through the tuned kernels, True (lam, phi, kk, ll evolve as well) through a kernel of its own.
+  * `model_config['bvf']` is the reference's scalar or (EXTENSION) an array on `grids`.  Both
+    `HPROP_GLOBAL` branches run on the GPU: False (the driver's, raytracer.py:38) through the tuned kernels, True
+    (lam, phi, kk, ll evolve as well) and / or a bvf array (drr, dmm evolve as well) through the general stage kernel.
   * The reference's other building blocks (`gradients`, `cg_*`, `dk_dt` ... `dv_dt`, `velocities_tanh`) are NOT
     mirrored: they are internals of its `rhs_default` (no caller in `raytracer.py`), and a numpy copy of them here
     would be a CPU path beside the GPU one.
@@ -411,8 +411,6 @@ def _check_scope():
     if np.ndim(b) != 0:                                          # EXTENSION: N as a column on grids
         if np.shape(b) != np.shape(grids):
             raise ValueError("model_config['bvf'] must be a scalar (as in the reference) or an array on lprop.grids")
-        if HPROP_GLOBAL:
-            raise NotImplementedError("a bvf column is supported with HPROP_GLOBAL = False only")
 
 
 def _same(a, b):
@@ -607,13 +605,13 @@ def _rhs(dt, var_in, flags):
     p = _prepare(var_in)
     t = p.rhs(dt, flags)
     z = lambda: np.zeros(np.shape(var_in[5]))
+    ddrr, ddmm = z(), z()
+    lam, phi, kk, ll = z(), z(), z(), z()
     if _bvf_column() is not None:                                # N(z) column: ddrr_st, ddmm_st != 0 (:641, :645)
         ddrr, ddmm = p.download_extents(tendencies=True)
-        return _pack([t['dens'], z(), z(), t['rr'], ddrr, z(), z(), t['mm'], ddmm, t['uu'], t['vv']])
     if HPROP_GLOBAL:                                             # lam, phi, kk, ll have tendencies too (:638-643)
         lam, phi, kk, ll = p.download_hprop(tendencies=True)
-        return _pack([t['dens'], lam, phi, t['rr'], z(), kk, ll, t['mm'], z(), t['uu'], t['vv']])
-    return _pack([t['dens'], z(), z(), t['rr'], z(), z(), z(), t['mm'], z(), t['uu'], t['vv']])
+    return _pack([t['dens'], lam, phi, t['rr'], ddrr, kk, ll, t['mm'], ddmm, t['uu'], t['vv']])
 
 
 def RK3(dt, var):

@@ -97,9 +97,10 @@ def test_hprop_call_order_and_scope_errors():
     with pytest.raises(_capi.MsgwError, match="msgw_upload_hprop"):
         p.step(60.0, 1)
     p.upload_hprop(lam, phi)
-    with pytest.raises(_capi.MsgwError, match="not available with HPROP"):
-        p.step(60.0, 1, _capi.DIRECT_SAT)
     p.step(60.0, 1)
+    p.upload_rays(dens, rr, drr, kk, ll, mm, dmm, phi, s.dkk, s.dll, s.rr_mm_area)   # lam, phi belonged to the old rays
+    with pytest.raises(_capi.MsgwError, match="msgw_upload_hprop"):
+        p.step(60.0, 1)
     p.close()
 
 

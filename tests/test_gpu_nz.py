@@ -172,8 +172,8 @@ def test_kat_frequency_conservation_on_the_gpu():
 
 
 def test_bvf_column_through_the_module_surface_and_scope():
-    """`model_config['bvf']` as an array on lprop.grids: RK3 and rhs_default return drr, dmm as evolving slots;
-    float32 contexts and the fused direct saturation say that they do not support the extension."""
+    """`model_config['bvf']` as an array on lprop.grids: RK3 and rhs_default return drr, dmm as evolving slots
+    (the combinations with HPROP, direct saturation, relaunch and a float32 state: tests/test_gpu_chain.py)."""
     import msgwam_amd.libprop as lprop
     s, st = _random_case(2000, 55, True, "uniform", True)
     col = _column(s.grids, 5)
@@ -199,14 +199,6 @@ def test_bvf_column_through_the_module_surface_and_scope():
     finally:
         lprop.set_model_setup(bvf=0.01, saturate_online=True)
         lprop.release_device()
-    p = make_prop_nz(s, st, col)
-    with pytest.raises(_capi.MsgwError, match="not available with an N"):
-        p.step(60.0, 1, _capi.RELAUNCH)
-    p.close()
-    p32 = _capi.Propagator(len(s.grid), 100, dtype="f32")
-    with pytest.raises(_capi.MsgwError, match="float64 only"):
-        p32.set_bvf_column(col)
-    p32.close()
 
 
 def test_standalone_saturation_and_projection_use_the_column():

@@ -16,5 +16,5 @@ MSGW_PERSIST=0 python bench.py --no-cpu-baseline --no-size-sweep --no-streamed-l
 python tools/variant_bench.py 1000000 f64 0.01 > $O/r03_variants_f64.txt 2>&1
 python tools/variant_bench.py 1250000 f32 0.01 > $O/r03_variants_f32.txt 2>&1
 python tools/tall_probe.py 1000000 201 301 451 601 801 > $O/r03_tall_probe.txt 2>&1
-for k in hprop nz nz_sat; do python tools/run_variant.py $k 1000000 30; done > $O/r03_chain_variants.txt 2>&1
+for k in hprop nz nz_sat hprop_nz hprop_sat hprop_f32 nz_f32 hprop_nz_f32 hprop_direct_rl; do python tools/run_variant.py $k 1000000 30; done > $O/r03_chain_variants.txt 2>&1
 echo BENCH_ALL_DONE

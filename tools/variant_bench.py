@@ -48,6 +48,6 @@ if "f64" in dtypes:
     p.upload_hprop(np.zeros(n), phi)
     p.step(120.0, 10); p.sync()
     t0 = time.perf_counter(); p.step(120.0, 50); p.sync(); dt = time.perf_counter() - t0
-    # per stage: read dens lam phi rr drr kk ll mm vol (+7 q, stages 1-2), write 6 (+6 q, stages 0-1): 27+14+18+12 words per step
-    print(f"{'HPROP on':16s}: {dt / 50 * 1e6:7.1f} us/step  ({n * 50 / dt:.3e} ray-steps/s, {n * 71 * 8 / (dt / 50) / 1e9:.0f} GB/s of 71 words per ray-step)")
+    # per stage: read dens lam phi rr drr kk ll mm vol (+6 q, stages 1-2), write 6 (+6 q, stages 0-1): 27+12+18+12 words per step
+    print(f"{'HPROP on':16s}: {dt / 50 * 1e6:7.1f} us/step  ({n * 50 / dt:.3e} ray-steps/s, {n * 69 * 8 / (dt / 50) / 1e9:.0f} GB/s of 69 words per ray-step)")
     p.close()
