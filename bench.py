@@ -128,13 +128,16 @@ def coupled_workload(w):
 
 
 def kernel_src_digest():
-    """Digest of the device code's sources: profiles/traffic.json entries carry the digest they were measured at, so a
-    line can say when its committed counter figures predate a kernel change (`traffic_stale`)."""
+    """Digest of the device code's sources (every header, tile_body.inc and the kern_*.hip translation units that
+    instantiate the kernels; not msgwam_hip.hip, the host side of the C ABI, which holds no device code):
+    profiles/traffic.json entries carry the digest they were measured at, so a line can say when its committed counter
+    figures predate a kernel change (`traffic_stale`).  The launch geometry, which the host side chooses, is part of
+    every entry's key."""
     import glob
     import hashlib
     h = hashlib.blake2b(digest_size=8)
     d = os.path.join(ROOT, "python-msgwam_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.hip"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "kern_*.hip"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()

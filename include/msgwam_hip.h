@@ -19,12 +19,16 @@
  * the reference-parity mode -- or float32 when the context is created with
  * MSGW_DTYPE_F32 (BASELINE config 5: half the bytes per ray, float32 per-ray
  * arithmetic; flux rows, their reduction and the mean-flow column stay float64).
- * Scope: scalar bvf as in the reference (a bvf COLUMN on grids is an extension, msgw_set_bvf_column, float64
- * contexts, HPROP off); both HPROP_GLOBAL branches (lib/libprop.py:5).  With
+ * Scope: scalar bvf as in the reference (a bvf COLUMN on grids is an extension, msgw_set_bvf_column);
+ * both HPROP_GLOBAL branches (lib/libprop.py:5).  With
  * HPROP_GLOBAL = False, the driver's configuration (raytracer.py:38), only dens,
  * rr, mm and the uu, vv columns evolve, so only those are copied
  * back; HPROP_GLOBAL = True adds lam, phi, kk, ll (msgw_upload_hprop /
- * msgw_download_hprop; float64 contexts only).
+ * msgw_download_hprop), a bvf column drr, dmm (msgw_download_extents).  Every
+ * combination of HPROP, bvf column, online / direct saturation, relaunch and
+ * ray type (float64, float32) is served; HPROP_GLOBAL = False with a scalar bvf
+ * by the tuned kernels (persistent form), everything else by the general
+ * per-stage kernel.
  */
 #ifndef MSGWAM_HIP_H
 #define MSGWAM_HIP_H
@@ -97,8 +101,14 @@ typedef struct {
     int32_t carried_flux;        /* 1: the last persistent launch took the flux of its initial state from the previous launch
                                     (same resident state, same kernel flavour) instead of a deposit-only pre-pass */
     double  algorithmic_bytes_total; /* SURVEY 8d bytes moved since create: words per ray-step of the path taken (35 coupled,
-                                    45 with online saturation, 6 fixed background; 71 HPROP, 63 N(z)) x elem_bytes x rays
-                                    x steps -- the yardstick of the roofline, not a hardware counter */
+                                    45 with online saturation, 6 fixed background; the general chain 3 L + 7 E, i.e. 69
+                                    HPROP, 55 N(z), 86 both) x elem_bytes x rays x steps -- the yardstick of
+                                    the roofline, not a hardware counter */
+    int32_t cooperative;         /* 1: the last persistent launch went through hipLaunchCooperativeKernel (the runtime
+                                    vouches for co-residency of the grid); 0: plain launch (several ranks, timed launches,
+                                    MSGW_COOP=0, or a device without cooperative launches) */
+    int32_t coop_refused;        /* cooperative launches the runtime refused since create (that call took the launch chain,
+                                    later ones the plain launch) */
 } msgw_counters_t;
 
 /* HPROP on: slots 1 and 2 (lam, phi) of the rays uploaded by the last msgw_upload_rays (same n). */
@@ -109,7 +119,7 @@ int msgw_download_hprop(msgw_ctx *ctx, int64_t n, int tendencies, double *lam, d
 /* EXTENSION (the reference has a scalar bvf only, lib/libprop.py:380, :398, :422, :583): buoyancy
  * frequency as a column bvf[ngrid-1] on lprop.grids, np.interp'ed to the height each expression is about (definition: DESIGN.md 6d).  The vertical group velocity then differs at rr +- drr/2
  * (lib/libprop.py:635-636), so drr and dmm evolve as well (:641, :645).  Call BEFORE msgw_upload_rays; NULL returns
- * to the scalar of msgw_set_config.  float64 contexts, HPROP off; steps run in a per-stage kernel of their own.
+ * to the scalar of msgw_set_config.  Steps run in the general per-stage kernel (any ray type, HPROP on or off).
  * In the limit N(z) = const the results are the reference's. */
 int msgw_set_bvf_column(msgw_ctx *ctx, const double *bvf);
 /* Slots 4, 8 (drr, dmm) of the resident rays -- they only change with an N(z) column -- or, tendencies != 0, their
@@ -118,6 +128,10 @@ int msgw_download_extents(msgw_ctx *ctx, int64_t n, int tendencies, double *drr,
 
 /* EXTENSION: the "broken ray" fraction of MSGW_RELAUNCH (default 1e-6; 0 disables that criterion). */
 int msgw_set_relaunch(msgw_ctx *ctx, double frac);
+/* EXTENSION: the (dens, rr, mm) a recycled slot returns to.  msgw_upload_rays sets them to the state it uploads; this
+ * call replaces them afterwards -- resuming from a checkpoint (the uploaded state is then not the source any more), or
+ * a source that changes in time.  n must be the resident ray count. */
+int msgw_set_relaunch_source(msgw_ctx *ctx, int64_t n, const double *dens, const double *rr, const double *mm);
 
 /* ABI version of the loaded library (== MSGW_ABI_VERSION). */
 int msgw_abi_version(void);

@@ -185,6 +185,7 @@ struct msgw_ctx {
     int *pstatus_host_dev = nullptr; // ... as the kernel sees it
     double *fcarry = nullptr;        // [2*(ng-2)] flux row of the final state of the last persistent launch (persist_kernel.h)
     int carry = 1;                   // MSGW_CARRY=0 (diagnostic, read when the context is created): always run the pre-pass
+    int coop = 1;                    // launch the persistent kernel with hipLaunchCooperativeKernel where the device has it (one rank per device; MSGW_COOP=0: plain launch)
     unsigned long long carry_key = 0;    // != 0: fcarry is F_0 of the resident state for a launch of this flavour key
     unsigned long long plan_key = 0;     // the cached launch plan (plan_persist costs three occupancy queries per call)
     std::vector<char> plan_blob;
@@ -841,7 +842,27 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.cout = ColOut{c->uu, c->vv, c->q_uu, c->q_vv};
     pa.dudz = c->dudz; pa.dvdz = c->dvdz; pa.slu = c->slu; pa.slv = c->slv;
     HIPCHK(c, hipMemsetAsync(c->pdone, 0, sizeof(unsigned int) * PDONE_WORDS, c->stream));
-    if (int rc = launch_struct(c, pl.fn, pl.grid, BLOCK, pl.lds, pa, nullptr, time_kernels)) return rc;
+    bool launched = false;
+    if (c->coop && !multi && !time_kernels) {
+        // hipLaunchCooperativeKernel: the RUNTIME vouches for co-residency of the whole grid (it refuses a grid that
+        // does not fit) instead of this file's reading of the occupancy query.  Measured: no cost (33.1 vs 33.0 us per
+        // step at config 3, 34.1 vs 34.4 with 20-step calls).  Kept to one rank per device: cooperative launches of
+        // several processes on one device take turns, which the in-kernel exchange between ranks that share a device
+        // (the 1-GPU rehearsals) could not survive; on distinct devices the peers' grids are separate launches anyway.
+        if (int rc = ensure_lds(c, pl.fn, pl.lds)) return rc;
+        void *args[] = {&pa};
+        const hipError_t e = hipLaunchCooperativeKernel(pl.fn, dim3(pl.grid), dim3(BLOCK), args, (unsigned int)pl.lds, c->stream);
+        if (e == hipSuccess) launched = true;
+        else {                                                 // refused: this call takes the launch chain, later ones the plain launch
+            (void)hipGetLastError();
+            c->coop = 0;
+            c->cnt.coop_refused += 1;
+            return MSGW_OK;
+        }
+    }
+    if (!launched)
+        if (int rc = launch_struct(c, pl.fn, pl.grid, BLOCK, pl.lds, pa, nullptr, time_kernels)) return rc;
+    c->cnt.cooperative = launched ? 1 : 0;
     *used = true;
     c->status_armed = true;
     c->cnt.persist_resident_tiles = pl.nres;
@@ -1056,7 +1077,8 @@ int enqueue_steps_chain(msgw_ctx *c, double dt, unsigned flags, int count)
 // SURVEY 8d accounting, words per ray-step of this chain = 3 L + 7 E: every stage reads L per-ray arrays (dens, rr, kk,
 // ll, mm; lam, phi or the per-ray f; drr and vol, or drr, dmm and dkk*dll with an N(z) column; the phase-volume factor
 // with online saturation) and writes the E evolving slots; their RK registers are written by stages 0, 1 and read by
-// stages 1, 2.  HPROP: 69, N(z): 55, N(z) + online saturation: 65, everything at once: 111.
+// stages 1, 2.  HPROP: 69, N(z): 55, N(z) + online saturation: 65, HPROP + N(z): 86, with online saturation: 96.
+// (Rounds 1-2 quoted 71 / 63 / 75: HPROP's two flux words included, N(z) with RK-register traffic in all three stages.)
 double chain_words_per_step(const msgw_ctx *c)
 {
     const int E = 2 + (c->sat_online ? 1 : 0) + (c->hprop ? 4 : 0) + (c->nz ? 2 : 0);
@@ -1291,6 +1313,16 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
     if (const char *e = std::getenv("MSGW_PERSIST")) c->persist = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_FIXED_NARROW")) c->fixed_narrow_force = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_CARRY")) c->carry = std::atoi(e) ? 1 : 0;
+    {
+        int has = 0;
+        if (hipDeviceGetAttribute(&has, hipDeviceAttributeCooperativeLaunch, c->device) != hipSuccess) { has = 0; (void)hipGetLastError(); }
+        c->coop = has ? 1 : 0;
+        // under a rocprofiler-sdk tool (rocprofv3 exports ROCP_TOOL_LIBRARIES) the process dies at exit() with a SIGSEGV
+        // in the runtime's teardown once a cooperative launch has happened (observed with rocprofv3 --kernel-trace and
+        // --pmc on ROCm 7.2, after all output files are written): the plain launch of the same kernel there
+        if (std::getenv("ROCP_TOOL_LIBRARIES")) c->coop = 0;
+    }
+    if (const char *e = std::getenv("MSGW_COOP")) c->coop = (c->coop && std::atoi(e)) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_BALANCE")) c->balance = std::atoi(e);
     if (const char *e = std::getenv("MSGW_PREFETCH")) c->prefetch = std::atoi(e) ? 1 : 0;
@@ -1578,6 +1610,20 @@ int msgw_set_relaunch(msgw_ctx *c, double frac)
     if (!(frac >= 0.0) || !(frac < 1.0)) return fail(c, MSGW_ERR_ARG, "relaunch fraction must be in [0, 1)");
     c->relaunch_frac = frac;
     drop_graph(c);
+    return MSGW_OK;
+}
+
+int msgw_set_relaunch_source(msgw_ctx *c, int64_t n, const double *dens, const double *rr, const double *mm)
+{
+    if (!c || !dens || !rr || !mm) return fail(c, MSGW_ERR_ARG, "NULL argument");
+    if (!c->have_rays || n != c->n) return fail(c, MSGW_ERR_ARG, "call msgw_upload_rays first, with the same n");
+    HIPCHK(c, hipSetDevice(c->device));
+    Staging st;
+    if (c->f32) HIPCHK(c, hipMalloc(&st.p, sizeof(double) * (size_t)n * 3));
+    if (int rc = upload_array(c, c->src_dens, dens, n, st.p)) return rc;
+    if (int rc = upload_array(c, c->src_rr, rr, n, st.p ? st.p + n : nullptr)) return rc;
+    if (int rc = upload_array(c, c->src_mm, mm, n, st.p ? st.p + 2 * n : nullptr)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));                // host buffers are the caller's
     return MSGW_OK;
 }
 

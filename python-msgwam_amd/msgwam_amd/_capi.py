@@ -28,7 +28,7 @@ EXPORTS = [
     "msgw_abi_version", "msgw_last_error", "msgw_create", "msgw_create_ex", "msgw_destroy", "msgw_set_config",
     "msgw_set_column", "msgw_upload_rays", "msgw_step", "msgw_rhs", "msgw_project",
     "msgw_project_arrays", "msgw_saturation", "msgw_download_rays", "msgw_download_column",
-    "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters", "msgw_set_relaunch", "msgw_upload_hprop", "msgw_download_hprop",
+    "msgw_sync", "msgw_comm_unique_id", "msgw_comm_init", "msgw_set_tuning", "msgw_counters", "msgw_set_relaunch", "msgw_set_relaunch_source", "msgw_upload_hprop", "msgw_download_hprop",
     "msgw_snapshot_create", "msgw_snapshot_download", "msgw_snapshot_destroy", "msgw_set_bvf_column", "msgw_download_extents",
     "msgw_probe_arith",
 ]
@@ -45,7 +45,8 @@ class Counters(C.Structure):
                 ("persist_resident_tiles", C.c_int32), ("elem_bytes", C.c_int32),
                 ("transport", C.c_int32), ("tenants", C.c_int32),
                 ("launch_grid", C.c_int32), ("launch_ray_workgroups", C.c_int32), ("launch_reducers", C.c_int32),
-                ("fixed_narrow", C.c_int32), ("carried_flux", C.c_int32), ("algorithmic_bytes_total", C.c_double)]
+                ("fixed_narrow", C.c_int32), ("carried_flux", C.c_int32), ("algorithmic_bytes_total", C.c_double),
+                ("cooperative", C.c_int32), ("coop_refused", C.c_int32)]
 
 
 class MsgwError(RuntimeError):
@@ -85,6 +86,7 @@ def load_library():
     lib.msgw_set_tuning.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.msgw_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
     lib.msgw_set_relaunch.argtypes = [C.c_void_p, C.c_double]
+    lib.msgw_set_relaunch_source.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp]
     lib.msgw_upload_hprop.argtypes = [C.c_void_p, C.c_int64, _dp, _dp]
     lib.msgw_download_hprop.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp, _dp, _dp, _dp]
     lib.msgw_snapshot_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -131,6 +133,7 @@ class Propagator:
         self.lib = load_library()
         self.ctx = C.c_void_p()
         self.ngrid, self.cap, self.n, self.dtype = int(ngrid), int(nray_cap), 0, dtype
+        self._given = {}            # what save_checkpoint needs besides the device state (references, no copies)
         rc = self.lib.msgw_create_ex(C.byref(self.ctx), int(device), self.cap, self.ngrid,
                                      DTYPE_F32 if dtype == "f32" else 0)
         if rc:
@@ -155,6 +158,8 @@ class Propagator:
     def set_config(self, bvf, phi0, kappa, saturate_online, hprop=False):
         self._chk(self.lib.msgw_set_config(self.ctx, float(bvf), float(coriolis(phi0)), float(kappa),
                                            int(bool(saturate_online)), int(bool(hprop))), "msgw_set_config")
+        self._given["config"] = np.array([float(bvf), float(phi0), float(kappa), float(bool(saturate_online)),
+                                          float(bool(hprop))])
 
     def set_column(self, grid, grids, rhobar, pressure_gradient, uu, vv):
         a = [_c(x) for x in (grid, grids, rhobar, pressure_gradient, uu, vv)]
@@ -163,6 +168,7 @@ class Propagator:
                 or a[3].shape != (2, nc) or a[4].shape != (nc,) or a[5].shape != (nc,):
             raise ValueError("column arrays do not match ngrid")
         self._chk(self.lib.msgw_set_column(self.ctx, *[_p(x) for x in a]), "msgw_set_column")
+        self._given.update(grid=a[0], grids=a[1], rhobar=a[2], pressure_gradient=a[3])
 
     def upload_rays(self, dens, rr, drr, kk, ll, mm, dmm, phi, dkk, dll, rr_mm_area):
         n = len(dens)
@@ -170,6 +176,8 @@ class Propagator:
         a = [_c(np.broadcast_to(x, (n,))) for x in (dens, rr, drr, kk, ll, mm, dmm, fray, dkk, dll, rr_mm_area)]
         self._chk(self.lib.msgw_upload_rays(self.ctx, n, *[_p(x) for x in a]), "msgw_upload_rays")
         self.n = n
+        self._given.update(drr=a[2], kk=a[3], ll=a[4], dmm=a[6], phi_static=_c(np.broadcast_to(phi, (n,))), dkk=a[8],
+                           dll=a[9], rr_mm_area=a[10], src_dens=a[0], src_rr=a[1], src_mm=a[5])
 
     def set_tuning(self, blocks_per_cu=4, graph_steps=0):
         self._chk(self.lib.msgw_set_tuning(self.ctx, int(blocks_per_cu), int(graph_steps)), "msgw_set_tuning")
@@ -178,11 +186,13 @@ class Propagator:
         """EXTENSION: N as a column on grids (None: back to the scalar of set_config).  Before upload_rays."""
         if bvf is None:
             self._chk(self.lib.msgw_set_bvf_column(self.ctx, None), "msgw_set_bvf_column")
+            self._given.pop("bvf_column", None)
             return
         b = _c(bvf)
         if b.shape != (self.ngrid - 1,):
             raise ValueError("the bvf column must have ngrid-1 values (on grids)")
         self._chk(self.lib.msgw_set_bvf_column(self.ctx, _p(b)), "msgw_set_bvf_column")
+        self._given["bvf_column"] = b
 
     def download_extents(self, tendencies=False, which=("drr", "dmm")):
         """Slots 4, 8 (drr, dmm; they evolve only with an N(z) column), or their tendencies after rhs()."""
@@ -206,6 +216,13 @@ class Propagator:
     def set_relaunch(self, frac=1e-6):
         """EXTENSION (not in the reference): broken-ray fraction of the RELAUNCH flag."""
         self._chk(self.lib.msgw_set_relaunch(self.ctx, float(frac)), "msgw_set_relaunch")
+        self._given["relaunch_frac"] = np.array(float(frac))
+
+    def set_relaunch_source(self, dens, rr, mm):
+        """EXTENSION: the (dens, rr, mm) a recycled slot returns to (default: the state upload_rays was given)."""
+        a = [_c(np.broadcast_to(x, (self.n,))) for x in (dens, rr, mm)]
+        self._chk(self.lib.msgw_set_relaunch_source(self.ctx, self.n, *[_p(x) for x in a]), "msgw_set_relaunch_source")
+        self._given.update(src_dens=a[0], src_rr=a[1], src_mm=a[2])
 
     # -- hot path --------------------------------------------------------------
     def step(self, dt, nsteps=1, flags=0):
@@ -287,6 +304,69 @@ class Propagator:
     def snapshot_free(self, snap):
         if getattr(self, "ctx", None):
             self.lib.msgw_snapshot_destroy(self.ctx, snap[0])
+
+    # -- checkpoint / resume ----------------------------------------------------
+    # the reference keeps its whole history in RAM (raytracer.py:125-136) and writes nothing; here the
+    # state lives in HBM, so a run that is to survive its process needs a file.  One .npz (numpy's own container,
+    # read back with allow_pickle=False): the evolving slots as they are on the device NOW, and the configuration,
+    # column and static per-ray arrays this object was given (kept by reference, not copied).
+    CHECKPOINT_FORMAT = 1
+
+    def save_checkpoint(self, path, **meta):
+        """Write everything `load_checkpoint` needs to continue this run; `meta` (numbers / small arrays, e.g. step=...)
+        is stored beside it under 'meta_<name>'.  Blocking (it downloads the state)."""
+        g = self._given
+        need = ("config", "grid", "drr")
+        if any(k not in g for k in need):
+            raise MsgwError("save_checkpoint: set_config, set_column and upload_rays come first")
+        hprop, nz = bool(g["config"][4]), "bvf_column" in g
+        out = {k: g[k] for k in ("config", "grid", "grids", "rhobar", "pressure_gradient", "phi_static", "dkk", "dll",
+                                 "rr_mm_area", "src_dens", "src_rr", "src_mm")}
+        out["dens"], out["rr"], out["mm"] = self.download_rays()
+        out["uu"], out["vv"] = self.download_column()
+        out["drr"], out["dmm"], out["kk"], out["ll"] = g["drr"], g["dmm"], g["kk"], g["ll"]
+        if nz:
+            out["bvf_column"] = g["bvf_column"]
+            out["drr"], out["dmm"] = self.download_extents()
+        if hprop:
+            out["lam"], out["phi"], out["kk"], out["ll"] = self.download_hprop()
+        if "relaunch_frac" in g:
+            out["relaunch_frac"] = g["relaunch_frac"]
+        out["format"] = np.array(self.CHECKPOINT_FORMAT)
+        out["ngrid"] = np.array(self.ngrid)
+        out["float32_state"] = np.array(self.dtype == "f32")
+        for k, v in meta.items():
+            out["meta_" + k] = np.asarray(v)
+        with open(path, "wb") as f:                            # (np.savez would append ".npz" to a bare name)
+            np.savez(f, **out)
+
+    @classmethod
+    def load_checkpoint(cls, path, device=0, nray_cap=None):
+        """A new context that continues where `save_checkpoint` stopped; returns (propagator, meta dict).
+        float64 contexts resume bit for bit (what the next step computes from is exactly what was on the device)."""
+        with np.load(path, allow_pickle=False) as z:
+            d = {k: z[k] for k in z.files}
+        if int(d["format"]) != cls.CHECKPOINT_FORMAT:
+            raise MsgwError(f"checkpoint format {int(d['format'])}, this build reads {cls.CHECKPOINT_FORMAT}")
+        n = len(d["dens"])
+        p = cls(int(d["ngrid"]), int(nray_cap or n), device=device, dtype="f32" if bool(d["float32_state"]) else "f64")
+        try:
+            bvf, phi0, kappa, sat, hprop = d["config"]
+            p.set_config(bvf, phi0, kappa, bool(sat), hprop=bool(hprop))
+            if "bvf_column" in d:
+                p.set_bvf_column(d["bvf_column"])
+            p.set_column(d["grid"], d["grids"], d["rhobar"], d["pressure_gradient"], d["uu"], d["vv"])
+            p.upload_rays(d["dens"], d["rr"], d["drr"], d["kk"], d["ll"], d["mm"], d["dmm"], d["phi_static"], d["dkk"],
+                          d["dll"], d["rr_mm_area"])
+            if bool(hprop):
+                p.upload_hprop(d["lam"], d["phi"])
+            p.set_relaunch_source(d["src_dens"], d["src_rr"], d["src_mm"])
+            if "relaunch_frac" in d:
+                p.set_relaunch(float(d["relaunch_frac"]))
+        except Exception:
+            p.close()
+            raise
+        return p, {k[5:]: v for k, v in d.items() if k.startswith("meta_")}
 
     def probe_arith(self, x, d):
         """Test support: (sqrt(x), x / d) as the ray kernels evaluate them (include/msgwam_hip.h)."""

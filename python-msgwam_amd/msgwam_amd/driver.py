@@ -69,7 +69,10 @@ KEYS = ["dens", "lam", "phi", "rr", "drr", "kk", "ll", "mm", "dmm"]
 
 
 def run(nray=60, ngrid=101, dt=120, nt_max=1440, alpha=0.01, mode="resident", snapshot_every=1,
-        diagnostics=True, ref_quirks=True, progress=False):
+        diagnostics=True, ref_quirks=True, progress=False, checkpoint_path=None, checkpoint_every=0, resume_from=None):
+    """`checkpoint_path` + `checkpoint_every` (resident mode): the device state is written to that .npz every so many
+    steps (at history-row boundaries) and at the end; `resume_from`: continue such a file up to `nt_max` -- the history
+    rows before its step are not part of the file and stay zero (`stored` lists the rows that were filled)."""
     grid, grids, init_uu, init_vv = configure(ngrid)
     ic = initial_rays(nray, grids, alpha)
     saturate_online = lprop.model_config['saturate_online']
@@ -109,16 +112,25 @@ def run(nray=60, ngrid=101, dt=120, nt_max=1440, alpha=0.01, mode="resident", sn
                 print('progress: {0:.2f}%'.format(nt / nt_max * 100), end='\r')
         lprop.release_device()
     elif mode == "resident":
-        p = _capi.Propagator(ngrid, nray)
-        p.set_config(lprop.model_config['bvf'], lprop.model_config['phi0'], lprop.model_config['kappa'],
-                     saturate_online)
-        p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, init_uu, init_vv)
-        p.upload_rays(ic["dens"], ic["rr"], ic["drr"], ic["kk"], ic["ll"], ic["mm"], ic["dmm"], ic["phi"],
-                      ic["dkk"], ic["dll"], ic["area"])
+        nt = 0
+        if resume_from is not None:
+            p, meta = _capi.Propagator.load_checkpoint(resume_from)
+            nt = int(meta["step"])
+            if p.n != nray or p.ngrid != ngrid or float(meta["dt"]) != float(dt):
+                p.close()
+                raise ValueError("the checkpoint belongs to another experiment (nray, ngrid or dt differ)")
+            stored = []
+        else:
+            p = _capi.Propagator(ngrid, nray)
+            p.set_config(lprop.model_config['bvf'], lprop.model_config['phi0'], lprop.model_config['kappa'],
+                         saturate_online)
+            p.set_column(grid, grids, lprop.rhobar, lprop.pressure_gradient, init_uu, init_vv)
+            p.upload_rays(ic["dens"], ic["rr"], ic["drr"], ic["kk"], ic["ll"], ic["mm"], ic["dmm"], ic["phi"],
+                          ic["dkk"], ic["dll"], ic["area"])
         flags = 0
         if not saturate_online:
             flags = _capi.DIRECT_SAT_QUIRK if ref_quirks else _capi.DIRECT_SAT
-        nt = 0
+        last_ckpt = nt
         while nt < nt_max:
             k = min(snapshot_every, nt_max - nt)
             p.step(dt, k, flags)
@@ -131,6 +143,9 @@ def run(nray=60, ngrid=101, dt=120, nt_max=1440, alpha=0.01, mode="resident", sn
                 H[f"int_{kname}"][nt] = ic[kname]
             H["int_uu"][nt], H["int_vv"][nt] = uu, vv
             stored.append(nt)
+            if checkpoint_path and checkpoint_every and (nt - last_ckpt >= checkpoint_every or nt == nt_max):
+                p.save_checkpoint(checkpoint_path, step=nt, dt=dt)
+                last_ckpt = nt
         p.close()
     else:
         raise ValueError("mode must be 'dropin' or 'resident'")

@@ -271,6 +271,7 @@ def test_full_size_config3_properties_and_subsample():
     c = p.counters()                                           # the flavour bench.py times is the one held to the oracle
     assert c["persist_steps"] == 2 and c["persist_resident_tiles"] == 4 and c["launch_reducers"] > 0
     assert c["launch_grid"] == c["launch_ray_workgroups"] + c["launch_reducers"] + 1
+    assert c["cooperative"] == 1 and c["coop_refused"] == 0        # the runtime vouches for the grid's co-residency
     got = gpu_state(p, st)
     assert np.array_equal(got[0], st[0])                       # dens constant without saturation
     check_state(got, want, 1e-10, 1e-11, "config3")
@@ -557,13 +558,15 @@ def test_flux_carried_between_calls(monkeypatch):
     st[0] = st[0] * 1e-3
     want = COracle(s).step(60.0, 9, st)
 
-    def run(carry):
+    def run(carry, coop=1):
         monkeypatch.setenv("MSGW_CARRY", "1" if carry else "0")
+        monkeypatch.setenv("MSGW_COOP", str(coop))
         p = make_prop(s, st)
         flags = []
         for k in (2, 3, 4):
             p.step(60.0, k)
             flags.append(p.counters()["carried_flux"])
+            assert p.counters()["cooperative"] == coop
         out = gpu_state(p, st)
         p.close()
         return out, flags
@@ -571,6 +574,11 @@ def test_flux_carried_between_calls(monkeypatch):
     a, fa = run(True)
     b, fb = run(False)
     assert fa == [0, 1, 1] and fb == [0, 0, 0]
+    # a plain launch instead of hipLaunchCooperativeKernel: the same kernel, the same bits
+    a0, _ = run(True, coop=0)
+    for k, x, y in zip(STATE_KEYS, a0, a):
+        assert np.array_equal(x, y, equal_nan=True), k
+    monkeypatch.delenv("MSGW_COOP")
     check_state(a, want, 1e-10, 1e-11, "carried")
     check_state(b, want, 1e-10, 1e-11, "pre-pass")
     check_state(a, b, 1e-12, 1e-12, "carried vs pre-pass")
