@@ -638,6 +638,7 @@ def main():
                        "launch_workgroups": c1.get("launch_grid", 0),
                        "launch_ray_workgroups": c1.get("launch_ray_workgroups", 0),
                        "launch_reducer_workgroups": c1.get("launch_reducers", 0),
+                       "cooperative_launch": bool(c1.get("cooperative", 0)),
                        "per_stage_kernel_workgroups": c1["blocks"],
                        "register_resident_tiles_per_workgroup": nres,
                        **({"one_ray_per_lane": bool(narrow)} if wl == "config2" else {}),
