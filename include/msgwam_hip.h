@@ -221,10 +221,12 @@ int msgw_saturation(msgw_ctx *ctx, int64_t n, double dt, int direct,
                     const double *dkk, const double *dll, const double *rr_mm_area,
                     double *out);
 
-/* Test support (no reference counterpart): the float64 square root and the division by a constant d exactly as the ray
- * kernels evaluate them (IEEE sqrt; Markstein's x / d for d >= 1; lib/libprop.py:383, :124, :694 are what they stand for), element by element on x [n] -> out_sqrt [n], out_div [n], so that the parity tests can hold
- * them bit for bit to numpy's sqrt(x) and x / d over the whole exponent range. */
-int msgw_probe_arith(msgw_ctx *ctx, int64_t n, const double *x, double d, double *out_sqrt, double *out_div);
+/* Test support (no reference counterpart): the float64 square root, the division by a constant d and (y != NULL) the
+ * division x[i] / y[i] exactly as the ray kernels evaluate them (lib/libprop.py:383, :448, :124, :694 are what they stand
+ * for), element by element on x [n] -> out_sqrt [n], out_div [n], out_quot [n], so that the parity tests can hold them bit
+ * for bit to numpy's sqrt(x), x / d and x / y over the domains csrc/real.h states, special values included. */
+int msgw_probe_arith(msgw_ctx *ctx, int64_t n, const double *x, double d, double *out_sqrt, double *out_div,
+                     const double *y, double *out_quot);
 
 /* Copy the evolving slots back (blocking). Any pointer may be NULL. */
 int msgw_download_rays(msgw_ctx *ctx, int64_t n, double *dens, double *rr, double *mm);

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(BLOCK, 2) k_ray_stage_chain(const ChainArgsT<T
             dispersion(kk[r], ll[r], mm[r], f2, bvf2c, kh2, m2, vk2, om, cgr);       // :369-383, :434-448
             if (!NZ) { cg_u = cgr; cg_d = cgr; }
             kh2s[r] = kh2; Ncs[r] = N_c;
-            const T st_rr = T(.5) * (cg_d + cg_u);                                  // :640
+            const T st_rr = NZ ? T(.5) * (cg_d + cg_u) : cgr;                       // :640 (scalar bvf: exactly cgr)
             const T st_drr = NZ ? cg_u - cg_d : T(0);                               // :641
             const Bracket<T> bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
             const quad_t sh = s_sh[bk.j];

@@ -95,12 +95,14 @@ __global__ void k_nz_prepare(long long n, const double *dkk, const double *dll, 
 // Arithmetic probe (msgw_probe_arith): the float64 square root and the exact constant division AS THE RAY KERNELS
 // EVALUATE THEM (sqrt_, div_const), element by element on caller arrays, so that a test can hold them bit for bit to
 // numpy over the whole exponent range (zeros, denormals, infinities, NaNs and negative arguments included).
-__global__ void k_probe_arith(long long n, const double *x, double d, double c, int ok, double *out_sqrt, double *out_div)
+__global__ void k_probe_arith(long long n, const double *x, double d, double c, int ok, double *out_sqrt, double *out_div,
+                              const double *y, double *out_quot)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out_sqrt[i] = sqrt_(x[i]);
     out_div[i] = div_const(x[i], d, c, ok);
+    if (y) out_quot[i] = div_(x[i], y[i]);
 }
 
 // Self-test of the node-level exchange, run once by every rank when the communicator is set up:

@@ -1818,20 +1818,24 @@ int msgw_saturation(msgw_ctx *c, int64_t n, double dt, int direct, const double 
     return rc;
 }
 
-int msgw_probe_arith(msgw_ctx *c, int64_t n, const double *x, double d, double *out_sqrt, double *out_div)
+int msgw_probe_arith(msgw_ctx *c, int64_t n, const double *x, double d, double *out_sqrt, double *out_div,
+                     const double *y, double *out_quot)
 {
-    if (!c || !x || !out_sqrt || !out_div || n < 1) return fail(c, MSGW_ERR_ARG, "bad arguments");
+    if (!c || !x || !out_sqrt || !out_div || n < 1 || (y && !out_quot)) return fail(c, MSGW_ERR_ARG, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     double *buf = nullptr;
-    HIPCHK(c, hipMalloc(&buf, sizeof(double) * (size_t)n * 3));
+    const size_t B = sizeof(double) * (size_t)n;
+    HIPCHK(c, hipMalloc(&buf, B * 5));
     int rc = MSGW_OK;
-    if (hipMemcpyAsync(buf, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    if (hipMemcpyAsync(buf, x, B, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        (y && hipMemcpyAsync(buf + 3 * n, y, B, hipMemcpyHostToDevice, c->stream) != hipSuccess))
         rc = fail(c, MSGW_ERR_HIP, "H2D failed in msgw_probe_arith");
     if (rc == MSGW_OK)
         rc = launch_list(c, probe_arith_kernel(), (unsigned)((n + 255) / 256), 256, (long long)n, (const double *)buf, d, 1.0 / d,
-                         markstein_ok(d), buf + n, buf + 2 * n);
-    if (rc == MSGW_OK && (hipMemcpyAsync(out_sqrt, buf + n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                          hipMemcpyAsync(out_div, buf + 2 * n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess))
+                         markstein_ok(d), buf + n, buf + 2 * n, (const double *)(y ? buf + 3 * n : nullptr), buf + 4 * n);
+    if (rc == MSGW_OK && (hipMemcpyAsync(out_sqrt, buf + n, B, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                          hipMemcpyAsync(out_div, buf + 2 * n, B, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                          (y && hipMemcpyAsync(out_quot, buf + 4 * n, B, hipMemcpyDeviceToHost, c->stream) != hipSuccess)))
         rc = fail(c, MSGW_ERR_HIP, "D2H failed in msgw_probe_arith");
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == MSGW_OK) rc = fail(c, MSGW_ERR_HIP, "sync failed in msgw_probe_arith");
     (void)hipFree(buf);

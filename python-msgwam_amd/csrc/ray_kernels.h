@@ -1129,7 +1129,7 @@ __global__ void __launch_bounds__(NARROW ? 64 : BLOCK) k_ray_step_fixed(const St
                 const T vk2 = kh2 + m2;
                 const T om = sqrt_(div_(a.bvf2 * kh2 + f2 * m2, vk2));
                 const T cgr = div_(div_(-mm[r] * (om * om - f2), om), vk2);
-                const T st_rr = T(.5) * (cgr + cgr);
+                const T st_rr = cgr;                                   // = .5 * (cgr + cgr) exactly (:640, see tile_body.inc)
                 const Bracket<T> bk = interp_locate(rr[r], s_xg, ni, a.xg0, a.xg_last, a.xg0, a.inv_dzg);
                 const quad_t sh = s_sh[bk.j];
                 const T gu = interp_eval(rr[r], bk, sh.x, sh.y);

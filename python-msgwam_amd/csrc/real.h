@@ -95,18 +95,61 @@ __device__ __forceinline__ float min1(float a, float b) { float r; asm("v_min_f3
 
 template <typename T> __device__ __forceinline__ T real_inf() { return std::numeric_limits<T>::infinity(); }
 
-// Division and square root of the per-ray arithmetic.  float64: IEEE (correctly rounded, bit-comparable with numpy).
+// Division and square root of the per-ray arithmetic.  float64: correctly rounded (bit-comparable with numpy) on the
+// operands of this physics -- the LEAN forms below are hipcc's own IEEE expansions WITHOUT the parts that only serve
+// extreme exponents: the two v_div_scale / the scaling half of v_div_fmas of a division (12 -> 9 VALU instructions),
+// the pre-scaling of arguments below 2^-767, its select and the two v_ldexp of a square root (19 -> 13).  Same
+// operations in the same order otherwise, so wherever hipcc's sequence would not have scaled the bits are the same:
+//   x / y        finite operands with 2^-968 <= |x|, 2^-1022 <= |y| <= 2^1021, 2^-1022 <= |x / y| < 2^1024 (beyond that the
+//                Newton residual, the reciprocal or the quotient leave the normal range); zeros, infinities and NaNs in either operand are put
+//                right by v_div_fixup as in hipcc's expansion;
+//   sqrt(x)      2^-767 <= x < inf; +-0, +inf, negative arguments and NaN by one class test.
+// The ray equations divide and take roots of frequencies, wavenumbers, densities and their squares (1e-30 .. 1e30);
+// tests/test_gpu_parity.py::test_device_sqrt_and_division_are_correctly_rounded holds both to numpy bit for bit over those
+// domains and the special values.  Why: the ray kernels are bound by VALU issue -- timing-only builds
+// with a 1-instruction square root / a 2-instruction division put the three roots of a fixed-background RK3 step at 13 %
+// and its nine divisions at 25 % of config 2's time (4.5 % / 7.5 % of config 3's).  -DMSGW_LEAN_ARITH=0: x / y and sqrt(x)
+// as hipcc expands them.
 // float32 is the throughput mode without a bit-level pin: v_rcp_f32 / v_sqrt_f32 (1 ulp each; x * rcp(y) <= 2 ulp)
 // instead of the ~12-instruction IEEE sequences -- the hot loop has ~9 divisions and 2 square roots per ray-stage
 // (measured at config 5: 84 -> 63 us per step).  Operands are far from the denormal range (wavenumbers 1e-6..1e-2,
 // frequencies ~1e-3, densities 1e-15..1e20).
-__device__ __forceinline__ double div_(double x, double y) { return x / y; }
+#ifndef MSGW_LEAN_ARITH
+#define MSGW_LEAN_ARITH 1
+#endif
+__device__ __forceinline__ double div_(double x, double y)
+{
+#if MSGW_LEAN_ARITH
+    double r = __builtin_amdgcn_rcp(y);
+    double e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-y, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = x * r;
+    e = __builtin_fma(-y, q, x);                             // exact remainder
+    return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), y, x);
+#else
+    return x / y;
+#endif
+}
 __device__ __forceinline__ float div_(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
-// (Round 3 measured a 10-instruction float64 square root for 2^-767 <= x < inf -- hipcc's own chain without the scaling of
-// tiny arguments and the class test, bit for bit numpy's on 2e6 inputs -- behind one rarely-true test: 9 of ~102 VALU
-// instructions of a fixed-background ray-stage less, and the same 1.56 us per step at 1e5 rays and 33.4 at config 3:
-// those kernels wait on dependent results, they do not run out of issue slots.  Not kept.)
-__device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ double sqrt_(double x)
+{
+#if MSGW_LEAN_ARITH
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;          // +-0 and +inf are their own roots (0x260: -0 | +0 | +inf)
+#else
+    return sqrt(x);
+#endif
+}
 __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
 // v_div_fixup: the quotient q of x / d with the special cases of IEEE division put right (see div_const)
 __device__ __forceinline__ double div_fixup_(double q, double d, double x) { return __builtin_amdgcn_div_fixup(q, d, x); }

@@ -94,7 +94,7 @@ def load_library():
     lib.msgw_set_bvf_column.argtypes = [C.c_void_p, _dp]
     lib.msgw_download_extents.argtypes = [C.c_void_p, C.c_int64, C.c_int, _dp, _dp]
     lib.msgw_snapshot_destroy.argtypes = [C.c_void_p, C.c_void_p]
-    lib.msgw_probe_arith.argtypes = [C.c_void_p, C.c_int64, _dp, C.c_double, _dp, _dp]
+    lib.msgw_probe_arith.argtypes = [C.c_void_p, C.c_int64, _dp, C.c_double, _dp, _dp, _dp, _dp]
     if lib.msgw_abi_version() != 3:
         raise MsgwError("libmsgwam_hip.so has an unexpected ABI version")
     _lib = lib
@@ -368,12 +368,17 @@ class Propagator:
             raise
         return p, {k[5:]: v for k, v in d.items() if k.startswith("meta_")}
 
-    def probe_arith(self, x, d):
-        """Test support: (sqrt(x), x / d) as the ray kernels evaluate them (include/msgwam_hip.h)."""
+    def probe_arith(self, x, d, y=None):
+        """Test support: (sqrt(x), x / d[, x / y]) as the ray kernels evaluate them (include/msgwam_hip.h)."""
         x = _c(x)
         s, q = np.empty(len(x)), np.empty(len(x))
-        self._chk(self.lib.msgw_probe_arith(self.ctx, len(x), _p(x), float(d), _p(s), _p(q)), "msgw_probe_arith")
-        return s, q
+        if y is None:
+            self._chk(self.lib.msgw_probe_arith(self.ctx, len(x), _p(x), float(d), _p(s), _p(q), None, None), "msgw_probe_arith")
+            return s, q
+        y = _c(np.broadcast_to(y, x.shape))
+        t = np.empty(len(x))
+        self._chk(self.lib.msgw_probe_arith(self.ctx, len(x), _p(x), float(d), _p(s), _p(q), _p(y), _p(t)), "msgw_probe_arith")
+        return s, q, t
 
     def sync(self):
         self._chk(self.lib.msgw_sync(self.ctx), "msgw_sync")

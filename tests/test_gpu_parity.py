@@ -613,30 +613,40 @@ def test_flux_carried_between_calls(monkeypatch):
 
 
 def test_device_sqrt_and_division_are_correctly_rounded():
-    """The kernels' float64 square root and the exact division by a constant (Markstein's x * c corrected by two FMAs,
-    special cases by v_div_fixup; d >= 1: grid spacings in metres and the 3 of the RK scheme, so a finite x never
-    overflows) against numpy, BIT FOR BIT, on 2e6 arguments over the whole exponent range incl. zeros, denormals,
-    infinities, NaNs, negative values."""
+    """The kernels' float64 square root, division and exact division by a constant against numpy, BIT FOR BIT, on 2e6
+    arguments: the square root for 2^-767 <= x < inf and +-0, inf, NaN, negative arguments; x / y for finite operands with
+    |x| >= 2^-968, 2^-1022 <= |y| <= 2^1021 and a quotient in the normal range, and every combination of zeros, infinities and NaNs
+    (csrc/real.h: hipcc's IEEE expansions without the parts that serve the extreme exponents beyond); Markstein's x / d for
+    d >= 1 (grid spacings in metres and the 3 of the RK scheme) over the whole exponent range."""
     rng = np.random.default_rng(123)
     n = 2_000_000
     mant = rng.uniform(1.0, 2.0, n)
     expo = rng.integers(-1074, 1024, n)
     x = np.ldexp(mant, expo)
     x[: n // 4] = rng.uniform(1e-9, 1e-3, n // 4)                   # where omega^2 lives
-    x[n // 4: n // 4 + 1000] = np.ldexp(rng.uniform(1, 2, 1000), rng.integers(-770, -764, 1000))   # around the switch, 2^-767
+    x[n // 4: n // 4 + 1000] = np.ldexp(rng.uniform(1, 2, 1000), rng.integers(-767, -760, 1000))   # the edge of sqrt's domain
     sign = rng.random(n) < 0.2
     x[sign] = -x[sign]
-    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 2.0 ** -767, np.nextafter(2.0 ** -767, 0), 5e-324, 2.0 ** -1022,
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 2.0 ** -767, 5e-324, 2.0 ** -1022,
                         np.finfo(np.float64).max, 1.0, 4.0, 2.0, 3.0])
     x[-len(special):] = special
+    # denominators: the exponent range of the physics and beyond, and the special values against every special numerator
+    y = np.ldexp(rng.uniform(1.0, 2.0, n), rng.integers(-1022, 1023, n)) * np.where(rng.random(n) < 0.3, -1.0, 1.0)
+    y[: n // 2] = rng.uniform(1e-12, 1e3, n // 2) * np.where(rng.random(n // 2) < 0.3, -1.0, 1.0)
+    ns = len(special)
+    x[-ns * ns - ns:-ns] = np.repeat(special, ns)
+    y[-ns * ns - ns:-ns] = np.tile(special, ns)
     p = _capi.Propagator(11, 16)
-    with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore", over="ignore", under="ignore"):
         want_s = np.sqrt(x)
+        want_t = x / y
+        sdom = (x >= 2.0 ** -767) | (x <= 0) | np.isnan(x)         # (negative arguments: NaN either way)
         for d in (3.0, 1000.0, 250.0, 7.5, 1.0):
-            got_s, got_q = p.probe_arith(x, d)
+            got_s, got_q, got_t = p.probe_arith(x, d, y)
             want_q = x / d
-            assert np.array_equal(got_s.view(np.uint64)[~np.isnan(want_s)], want_s.view(np.uint64)[~np.isnan(want_s)])
-            assert np.array_equal(np.isnan(got_s), np.isnan(want_s))
+            ok = sdom & ~np.isnan(want_s)
+            assert np.array_equal(got_s.view(np.uint64)[ok], want_s.view(np.uint64)[ok])
+            assert np.array_equal(np.isnan(got_s[sdom]), np.isnan(want_s[sdom]))
             ok = ~np.isnan(want_q)
             # (the sign of a zero quotient and quotients below 2^-960 -- where the exact remainder x - d * q of Markstein's
             # correction step is itself denormal: 1 ulp off between 2^-1022 and 2^-1019 -- are outside what div_const
@@ -646,4 +656,12 @@ def test_device_sqrt_and_division_are_correctly_rounded():
             assert np.array_equal(np.isnan(got_q), np.isnan(want_q))
             tiny = ok & ~normal
             assert np.all(np.abs(got_q[tiny] - want_q[tiny]) <= np.abs(want_q[tiny]) * 2.0 ** -52 + 5e-324 * 2)
+        # x / y: bit for bit on its domain, and on every special operand
+        spec = ~np.isfinite(x) | ~np.isfinite(y) | (x == 0) | (y == 0)
+        dom = spec | ((np.abs(x) >= 2.0 ** -968) & (np.abs(y) >= 2.0 ** -1022) & (np.abs(y) <= 2.0 ** 1021) &
+                      (np.abs(want_t) >= 2.0 ** -1022) & np.isfinite(want_t))
+        assert dom.sum() > 0.8 * n and spec.sum() >= 100
+        ok = dom & ~np.isnan(want_t)
+        assert np.array_equal(got_t.view(np.uint64)[ok], want_t.view(np.uint64)[ok])
+        assert np.array_equal(np.isnan(got_t[dom]), np.isnan(want_t[dom]))
     p.close()

@@ -4,12 +4,23 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", "prof", tag)
 out = {"tag": tag, "kernels": {}, "pmc": {}}
-for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+
+
+def newest(pattern):
+    """gpurun MERGES a call's output into the local gpurun_out/, so a pass directory can hold the csv files of several
+    runs (one per process id): only the most recent one belongs to the current sources."""
+    by_dir = collections.defaultdict(list)
+    for f in glob.glob(pattern, recursive=True):
+        by_dir[f.split(os.sep + tag + os.sep, 1)[1].split(os.sep)[0]].append(f)
+    return [max(fs, key=os.path.getmtime) for fs in by_dir.values()]
+
+
+for f in newest(os.path.join(src, "trace", "**", "*kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         out["kernels"][r["Name"]] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3,
                                          min_us=float(r["MinNs"]) / 1e3, max_us=float(r["MaxNs"]) / 1e3,
                                          total_ms=float(r["TotalDurationNs"]) / 1e6, pct=float(r["Percentage"]))
-for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+for f in newest(os.path.join(src, "pmc_*", "**", "*counter_collection.csv")):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
