@@ -105,8 +105,8 @@ typedef struct {
                                     HPROP, 55 N(z), 86 both) x elem_bytes x rays x steps -- the yardstick of
                                     the roofline, not a hardware counter */
     int32_t cooperative;         /* 1: the last persistent launch went through hipLaunchCooperativeKernel (the runtime
-                                    vouches for co-residency of the grid); 0: plain launch (several ranks, timed launches,
-                                    MSGW_COOP=0, or a device without cooperative launches) */
+                                    vouches for co-residency of the grid); 0: plain launch (several ranks, MSGW_COOP=0, under a
+                                    rocprofiler tool, or a device without cooperative launches) */
     int32_t coop_refused;        /* cooperative launches the runtime refused since create (that call took the launch chain,
                                     later ones the plain launch) */
 } msgw_counters_t;

@@ -843,7 +843,7 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
     pa.dudz = c->dudz; pa.dvdz = c->dvdz; pa.slu = c->slu; pa.slv = c->slv;
     HIPCHK(c, hipMemsetAsync(c->pdone, 0, sizeof(unsigned int) * PDONE_WORDS, c->stream));
     bool launched = false;
-    if (c->coop && !multi && !time_kernels) {
+    if (c->coop && !multi) {
         // hipLaunchCooperativeKernel: the RUNTIME vouches for co-residency of the whole grid (it refuses a grid that
         // does not fit) instead of this file's reading of the occupancy query.  Measured: no cost (33.1 vs 33.0 us per
         // step at config 3, 34.1 vs 34.4 with 20-step calls).  Kept to one rank per device: cooperative launches of
@@ -851,7 +851,13 @@ int run_persistent(msgw_ctx *c, double dt, unsigned flags, int count, bool time_
         // (the 1-GPU rehearsals) could not survive; on distinct devices the peers' grids are separate launches anyway.
         if (int rc = ensure_lds(c, pl.fn, pl.lds)) return rc;
         void *args[] = {&pa};
+        // (MSGW_TIME_KERNELS: hipLaunchCooperativeKernel takes no events, so the pair is recorded on the stream right
+        // around the launch -- nothing else is enqueued in between)
+        hipEvent_t *ev = time_kernels ? timing_events(c) : nullptr;
+        if (ev) HIPCHK(c, hipEventRecord(ev[0], c->stream));
         const hipError_t e = hipLaunchCooperativeKernel(pl.fn, dim3(pl.grid), dim3(BLOCK), args, (unsigned int)pl.lds, c->stream);
+        if (e == hipSuccess && ev) HIPCHK(c, hipEventRecord(ev[1], c->stream));
+        if (e != hipSuccess && ev) c->kev_used -= 2;
         if (e == hipSuccess) launched = true;
         else {                                                 // refused: this call takes the launch chain, later ones the plain launch
             (void)hipGetLastError();
