@@ -578,14 +578,15 @@ def main():
                             "achieved_is": "ALGORITHMIC bytes (SURVEY 8d) of one launch / its HIP-event duration; every ray "
                                            "streams through HBM once per RK stage on this path", **common}
             roofline["limiter"] = {
-                "config3": "VALU issue at 2 wavefronts per SIMD (dependent LDS / memory round trips inside the tile body) and "
-                           "the pass hand-off: the younger of a CU's two workgroups sets the pass period (DESIGN.md 6)",
+                "config3": "VALU issue inside the tiles (a pass of a ray workgroup: table 1.8 + tiles 7.2 + publish 1.2 us; the two "
+                           "workgroups of a CU do the first and the last at the same time) and the reduce chain, 9.6 us from the "
+                           "last row to the release, which is as long as a pass (DESIGN.md 6, 8; profiles/r03_persist_timeline.txt)",
                 "config4": "as config3, plus the rank sum on the reduce chain (DESIGN.md 5a)",
-                "config5": "latency at 2 wavefronts per SIMD; the deposit of a dispersed packet (wavefronts whose rays span "
-                           "many levels)",
-                "config2": "issue of dependent float64 chains (3 IEEE divisions + 1 square root per ray-stage); at 1e5 rays "
-                           "the chip holds 1.5 wavefronts per SIMD (one ray per lane), so the integer number of wavefronts "
-                           "per SIMD is part of the bound (DESIGN.md 4, K1f)"}.get(wl) if persist_steps else None
+                "config5": "VALU issue (online saturation is a second table look-up and two more divisions per ray-stage); the "
+                           "deposit of a dispersed packet (wavefronts whose rays span many levels)",
+                "config2": "VALU issue (84-92 % of the step's own issue time from two wavefronts per SIMD on); at 1e5 rays the "
+                           "chip holds 1.53 wavefronts per SIMD (one ray per lane): 539 SIMDs with two, 485 with one that finish "
+                           "early and idle (DESIGN.md 4, K1f; profiles/r03_config2_wave_count_probe.txt)"}.get(wl) if persist_steps else None
             if streamed is not None and streamed["kern_ms"]:
                 sc = streamed["counters"]
                 s_sec = streamed["kern_ms"] * 1e-3
