@@ -1235,7 +1235,8 @@ int project_resident(msgw_ctx *c, int var, const double *G, int nG, double *out)
     a.bvf2 = (T)std::pow(c->bvf, 2.0); a.f_uni = (T)c->f_uni; a.dz = (T)(G[1] - G[0]);
     a.cdz = T(1) / a.dz; a.mk_ok = markstein_ok(a.dz);
     a.r = ray_ptrs<T>(c);
-    if (c->nz) {                                               // N(z) column (float64 contexts): N at the ray centre rr
+    if (c->nz) {                                               // N(z) column: N at the ray centre rr, volume from the current dmm
+        a.dkdl = c->have_nz ? static_cast<const T *>(c->nz_dkdl) : nullptr;
         a.bvfcol = c->bvfcol; a.grids = c->grids; a.nc = c->ng - 1;
         a.gs0 = c->gs0; a.gs_last = c->gs_last; a.inv_dzs = 1.0 / c->dzs;
     }

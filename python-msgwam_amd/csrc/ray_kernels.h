@@ -1204,7 +1204,9 @@ struct ProjArgsT {
     const double *G;
     double *partial;      // [blocks][NP][nG-1]
     int *ranges;
-    // EXTENSION: N as a column on `grids` (float64 contexts; nullptr: the scalar in bvf2), taken at the ray centre
+    // EXTENSION: N as a column on `grids` (nullptr: the scalar in bvf2), taken at the ray centre; the resident rays'
+    // dmm then evolves, so their phase-space volume is |dkk*dll * dmm| of the CURRENT dmm (dkdl), not the upload's
+    const T *dkdl;
     const double *bvfcol, *grids;
     int nc;
     double gs0, gs_last, inv_dzs;
@@ -1270,6 +1272,12 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
             loadv(a.r.dmm(), i0, dmm);
             loadv(a.r.vol(), i0, vol);
             if (FVEC) loadv(a.r.fray(), i0, ff);
+            if (a.dkdl) {                                             // (kernel-uniform) N(z) column: dmm has evolved
+                T dk[RPT];
+                loadv(a.dkdl, i0, dk);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) vol[r] = fabs(dk[r] * dmm[r]);       // :137
+            }
 #pragma unroll
             for (int r = 0; r < RPT; ++r) {
                 lo[r] = rr[r] - T(.5) * drr[r];                       // :655 / raytracer.py:200-201
@@ -1293,12 +1301,10 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
             const T f = (FVEC || EXPL) ? ff[r] : a.f_uni;
             T kh2, m2, vk2, om, cgr;
             T bvf2 = a.bvf2;
-            if constexpr (std::is_same<T, double>::value) {
-                if (a.bvfcol) {                                       // (kernel-uniform) N at the ray centre
-                    const double zc = EXPL ? .5 * (zlo[r] + zup[r]) : zctr[r];
-                    const double N = interp_global(zc, a.grids, a.bvfcol, a.nc, a.gs0, a.gs_last, a.inv_dzs);
-                    bvf2 = N * N;
-                }
+            if (a.bvfcol) {                                           // (kernel-uniform) N at the ray centre
+                const double zc = EXPL ? .5 * ((double)zlo[r] + (double)zup[r]) : (double)zctr[r];
+                const double N = interp_global(zc, a.grids, a.bvfcol, a.nc, a.gs0, a.gs_last, a.inv_dzs);
+                bvf2 = (T)(N * N);
             }
             dispersion(kk[r], ll[r], mmid[r], f * f, bvf2, kh2, m2, vk2, om, cgr);
             if (NP == 2) { pay[0][r] = cgr * kk[r] * dens[r]; pay[NP - 1][r] = cgr * ll[r] * dens[r]; }   // :148-149

@@ -249,6 +249,15 @@ def test_standalone_saturation_and_projection_use_the_column():
         want = orc.wave_projection(dens, lo, up, kk, ll, mm - .5 * dmm, mm + .5 * dmm, phi, s.dkk, s.dll, dmm, s.grids,
                                    orc.bvf_at(s, rr), var=var)
         assert prof_err(np.atleast_2d(p.project(var, s.grids)), np.atleast_2d(want)) <= 1e-12, var
+    # ... and of the state two steps later: drr, dmm have evolved, and with them the rays' extents and phase-space volumes
+    p.step(60.0, 2)
+    cur = gpu_state_nz(p, st)
+    d2, r2, dr2, m2, dm2 = cur[0], cur[3], cur[4], cur[7], cur[8]
+    assert relerr(dm2, dmm) > 1e-4
+    for var in (0, 1, 2):
+        want = orc.wave_projection(d2, r2 - .5 * dr2, r2 + .5 * dr2, kk, ll, m2 - .5 * dm2, m2 + .5 * dm2, phi, s.dkk, s.dll, dm2,
+                                   s.grids, orc.bvf_at(s, r2), var=var)
+        assert prof_err(np.atleast_2d(p.project(var, s.grids)), np.atleast_2d(want)) <= 1e-12, ("after two steps", var)
     p.close()
     # a scalar context asked for "the context's column" says so
     q = _capi.Propagator(len(s.grid), 16)
