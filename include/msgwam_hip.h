@@ -192,8 +192,7 @@ int msgw_rhs(msgw_ctx *ctx, double dt, unsigned flags,
  * rays on an arbitrary uniform grid G [nG].  var 0, 1, 2 (cell centres): out is
  * [2][nG-1] for var 0 and [nG-1] otherwise (raytracer.py:213, :227); var 3, 4
  * (interfaces, :199-219): [nG] and [2][nG].  With an N(z) column the group velocity uses N at the ray centre rr.
- * The Coriolis parameter of a ray is the one of the latitude msgw_upload_rays was given -- with HPROP on, where the
- * latitude evolves, project the downloaded state with msgw_project_arrays instead (what lprop.wave_projection does). */
+ * With HPROP on the Coriolis parameter of a ray is that of its CURRENT latitude (lib/libprop.py:382). */
 int msgw_project(msgw_ctx *ctx, int var, const double *G, int nG, double *out);
 
 /* lprop.wave_projection(dens, lam, phi, rr_low, rr_up, kk, ll, mm_low, mm_up, dkk,

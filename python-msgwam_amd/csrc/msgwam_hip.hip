@@ -1235,6 +1235,10 @@ int project_resident(msgw_ctx *c, int var, const double *G, int nG, double *out)
     a.bvf2 = (T)std::pow(c->bvf, 2.0); a.f_uni = (T)c->f_uni; a.dz = (T)(G[1] - G[0]);
     a.cdz = T(1) / a.dz; a.mk_ok = markstein_ok(a.dz);
     a.r = ray_ptrs<T>(c);
+    if (c->hprop && c->have_hprop) {                           // HPROP: the Coriolis parameter of the current latitude
+        a.phi = static_cast<const T *>(c->phi);
+        a.two_rot = (T)(2 * 7.2921e-5);                        // 2 * ROT_EARTH (lib/libprop.py:4, :382)
+    }
     if (c->nz) {                                               // N(z) column: N at the ray centre rr, volume from the current dmm
         a.dkdl = c->have_nz ? static_cast<const T *>(c->nz_dkdl) : nullptr;
         a.bvfcol = c->bvfcol; a.grids = c->grids; a.nc = c->ng - 1;

@@ -1208,6 +1208,10 @@ struct ProjArgsT {
     // dmm then evolves, so their phase-space volume is |dkk*dll * dmm| of the CURRENT dmm (dkdl), not the upload's
     const T *dkdl;
     const double *bvfcol, *grids;
+    // HPROP_GLOBAL = True: the resident rays' latitude evolves, so their Coriolis parameter is 2 Omega sin(phi) of the
+    // CURRENT phi (:382), not the per-ray f of the upload (nullptr: HPROP off)
+    const T *phi;
+    T two_rot;
     int nc;
     double gs0, gs_last, inv_dzs;
 };
@@ -1272,6 +1276,12 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
             loadv(a.r.dmm(), i0, dmm);
             loadv(a.r.vol(), i0, vol);
             if (FVEC) loadv(a.r.fray(), i0, ff);
+            if (a.phi) {                                              // (kernel-uniform) HPROP: the latitude has evolved
+                T ph[RPT];
+                loadv(a.phi, i0, ph);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) ff[r] = a.two_rot * sin(ph[r]);
+            }
             if (a.dkdl) {                                             // (kernel-uniform) N(z) column: dmm has evolved
                 T dk[RPT];
                 loadv(a.dkdl, i0, dk);
@@ -1298,7 +1308,7 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
                 nlo[r] += 1;
                 lo[r] = T(-1e30); up[r] = T(1e30);
             }
-            const T f = (FVEC || EXPL) ? ff[r] : a.f_uni;
+            const T f = (FVEC || EXPL) ? ff[r] : (a.phi ? ff[r] : a.f_uni);
             T kh2, m2, vk2, om, cgr;
             T bvf2 = a.bvf2;
             if (a.bvfcol) {                                           // (kernel-uniform) N at the ray centre

@@ -271,19 +271,21 @@ def test_module_surface_with_hprop_and_a_bvf_column():
         lprop.release_device()
 
 
-def test_float32_resident_projection_with_a_column_and_hprop():
-    """`msgw_project` on a float32 state that carries an N(z) column and evolving kk, ll (HPROP): N at the resident ray
-    centre, the CURRENT kk, ll, drr, dmm -- against the numpy projection of the downloaded state."""
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-11), ("f32", 5e-5)])
+def test_resident_projection_with_a_column_and_hprop(dtype, tol):
+    """`msgw_project` on a state that carries an N(z) column and evolving phi, kk, ll (HPROP): N at the resident ray
+    centre, the CURRENT phi, kk, ll, drr, dmm -- against the numpy projection of the downloaded state."""
     s, st, col = _case(20_003, 451, False, True, True)
     st[0] = st[0] * 1e-3
-    p = make_chain_prop(s, st, True, col, dtype="f32")
+    p = make_chain_prop(s, st, True, col, dtype=dtype)
     p.step(60.0, 2)
     cur = chain_state(p, st, True, True)
     dens, lam, phi, rr, drr, kk, ll, mm, dmm = cur[:9]
+    assert not np.array_equal(phi, st[2])
     lo, up = rr - .5 * drr, rr + .5 * drr
     for var in (0, 1, 2):
-        want = orc.wave_projection(dens, lo, up, kk, ll, mm - .5 * dmm, mm + .5 * dmm, st[2], s.dkk, s.dll, dmm, s.grids,
+        want = orc.wave_projection(dens, lo, up, kk, ll, mm - .5 * dmm, mm + .5 * dmm, phi, s.dkk, s.dll, dmm, s.grids,
                                    orc.bvf_at(s, rr), var=var)
         got = p.project(var, s.grids)
-        assert prof_err(np.atleast_2d(got), np.atleast_2d(want)) <= 5e-5, var
+        assert prof_err(np.atleast_2d(got), np.atleast_2d(want)) <= tol, var
     p.close()
