@@ -289,3 +289,29 @@ def test_resident_projection_with_a_column_and_hprop(dtype, tol):
         got = p.project(var, s.grids)
         assert prof_err(np.atleast_2d(got), np.atleast_2d(want)) <= tol, var
     p.close()
+
+
+@pytest.mark.parametrize("dtype,ngrid,n", [("f32", 301, 6_007), ("f64", 600, 3_001), ("f32", 101, 1), ("f64", 101, 2)])
+def test_chain_on_tall_columns_and_tiny_ray_counts(dtype, ngrid, n):
+    """Everything on (HPROP, N(z), direct saturation, relaunch) where the launch geometry is unusual: columns with more
+    than 130 levels (sparse per-workgroup rows, the separate reduce kernel) and one or two rays (a single, mostly inert
+    tile)."""
+    from test_gpu_parity import _tall_case
+    rng = np.random.default_rng(ngrid + n)
+    if ngrid > 101:
+        s, st = _tall_case(ngrid, n, seed=21)
+    else:
+        s, st = _random_case(n, 460 + n, False, "vector", True)
+        st[0] = st[0] * 1e-3
+    st[1] = rng.uniform(0, 2 * np.pi, n)
+    st[2] = rng.uniform(-1.0, 1.0, n)
+    col = 0.01 * (1 + 0.25 * np.sin(s.grids / 23e3))
+    s.bvf, s.hprop = col, True
+    want, _, _ = oracle_loop(s, st, 60.0, 3, direct=2, relaunch=1e-6)
+    p = make_chain_prop(s, st, True, col, dtype=dtype)
+    p.set_relaunch(1e-6)
+    p.step(60.0, 1, _capi.DIRECT_SAT | _capi.RELAUNCH)
+    p.step(60.0, 2, _capi.DIRECT_SAT | _capi.RELAUNCH)
+    got = chain_state(p, st, True, True)
+    p.close()
+    close(got, want, 1e-10 if dtype == "f64" else 5e-5, (dtype, ngrid, n), outliers=0.0 if dtype == "f64" else 2e-3)
