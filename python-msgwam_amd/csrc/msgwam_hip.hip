@@ -1331,7 +1331,10 @@ int msgw_create_ex(msgw_ctx **out, int device, int64_t nray_cap, int ngrid, unsi
         // under a rocprofiler-sdk tool (rocprofv3 exports ROCP_TOOL_LIBRARIES) the process dies at exit() with a SIGSEGV
         // in the runtime's teardown once a cooperative launch has happened (observed with rocprofv3 --kernel-trace and
         // --pmc on ROCm 7.2, after all output files are written): the plain launch of the same kernel there
-        if (std::getenv("ROCP_TOOL_LIBRARIES")) c->coop = 0;
+        const char *pre = std::getenv("LD_PRELOAD");
+        if (std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_LIBRARY_CTOR") ||
+            (pre && (std::strstr(pre, "rocprofiler") || std::strstr(pre, "roctracer"))))
+            c->coop = 0;
     }
     if (const char *e = std::getenv("MSGW_COOP")) c->coop = (c->coop && std::atoi(e)) ? 1 : 0;
     if (const char *e = std::getenv("MSGW_SERVICE")) c->service = std::atoi(e) ? 1 : 0;
