@@ -1134,7 +1134,7 @@ __global__ void __launch_bounds__(NARROW ? 64 : BLOCK) k_ray_step_fixed(const St
                 const quad_t sh = s_sh[bk.j];
                 const T gu = interp_eval(rr[r], bk, sh.x, sh.y);
                 const T gv = interp_eval(rr[r], bk, sh.z, sh.w);
-                const T st_mm = (kk[r] * T(0) + ll[r] * T(0)) - (kk[r] * gu + ll[r] * gv);
+                const T st_mm = -(kk[r] * gu + ll[r] * gv);                       // :519-520 (see tile_body.inc)
                 T st_dens = T(0);
                 if (SAT) {
                     const T rr_f = rr[r] + st_rr * a.dt;
