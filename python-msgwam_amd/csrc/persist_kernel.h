@@ -812,7 +812,7 @@ __device__ __forceinline__ bool persist_stage(const PersistArgsT<T> p, const Per
 // neither), rhobar and the pressure gradient are read from global memory: 128 instead of 184 B of LDS per level.  A
 // compile-time variant: as a run-time option its pointer selection cost the default column 1.4 % (register allocation).
 template <typename T, bool SAT, bool FVEC, bool DIRECT, int NRES = 0, bool RL = false, bool LEAN = false>
-__global__ void __launch_bounds__(BLOCK, NRES > 0 ? ((MSGW_EXP3 && NRES == 2) ? 3 : 2) : 4) k_rk3_persist(const PersistArgsT<T> p)
+__global__ void __launch_bounds__(BLOCK, NRES > 0 ? 2 : 4) k_rk3_persist(const PersistArgsT<T> p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int TILE = Real<T>::TILE;

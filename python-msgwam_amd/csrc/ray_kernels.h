@@ -15,14 +15,6 @@
 #ifndef MSGW_PREFKL
 #define MSGW_PREFKL 1       // resident tiles read kk, ll one tile ahead (tile_body.inc)
 #endif
-#ifndef MSGW_PAIRDISP
-#define MSGW_PAIRDISP 0   // 1: the lagged dispersion relation of a lane's two float64 rays as ONE interleaved chain (dispersion_pair);
-                          // measured (round 3): config 3 33.8-33.9 vs 33.1-33.6 us per step -- the other workgroup's wavefront
-                          // on the SIMD already covers the chain's latency; off
-#endif
-#ifndef MSGW_EXP3
-#define MSGW_EXP3 0     // experiment: two evolving-only resident tiles at THREE workgroups per CU
-#endif
 
 namespace msgw {
 
@@ -634,61 +626,6 @@ __device__ __forceinline__ void dispersion(T kk, T ll, T mm, T f2, T bvf2, T &kh
     vk2 = kh2 + m2;
     om = sqrt_(div_(bvf2 * kh2 + f2 * m2, vk2));
     cgr = div_(div_(-mm * (om * om - f2), om), vk2);
-}
-
-// The same for the TWO rays of a lane at once, the two dependent chains INTERLEAVED operation by operation.  One chain
-// is ~60 instructions in sequence (division, square root, two divisions), each waiting ~12 cycles for the one before;
-// hipcc, at the register limit of the resident-tile kernels, emits ray 0's chain and then ray 1's, so a wavefront
-// spends ~1400 cycles per tile body waiting on them with only the CU's other workgroup to fill the SIMD.  Written out
-// here, the divisions and the square root are hipcc's OWN expansions (v_div_scale / v_rcp / four FMAs / v_div_fmas /
-// v_div_fixup; the scaled v_rsq chain with its class test), statement for statement, so every result is bit for bit the
-// one `x / y` and `sqrt(x)` give (held to numpy by test_device_sqrt_and_division_are_correctly_rounded through
-// msgw_probe_arith).
-__device__ __forceinline__ void div_ieee2(double x0, double y0, double x1, double y1, double &q0, double &q1)
-{
-    bool fa0, fa1, fb0, fb1;
-    const double s0 = __builtin_amdgcn_div_scale(x0, y0, false, &fa0), s1 = __builtin_amdgcn_div_scale(x1, y1, false, &fa1);
-    double r0 = __builtin_amdgcn_rcp(s0), r1 = __builtin_amdgcn_rcp(s1);
-    double e0 = fma(-s0, r0, 1.0), e1 = fma(-s1, r1, 1.0);
-    r0 = fma(r0, e0, r0); r1 = fma(r1, e1, r1);
-    e0 = fma(-s0, r0, 1.0); e1 = fma(-s1, r1, 1.0);
-    r0 = fma(r0, e0, r0); r1 = fma(r1, e1, r1);
-    const double t0 = __builtin_amdgcn_div_scale(x0, y0, true, &fb0), t1 = __builtin_amdgcn_div_scale(x1, y1, true, &fb1);
-    const double m0 = t0 * r0, m1 = t1 * r1;
-    const double g0 = fma(-s0, m0, t0), g1 = fma(-s1, m1, t1);
-    q0 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(g0, r0, m0, fb0), y0, x0);
-    q1 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(g1, r1, m1, fb1), y1, x1);
-    (void)fa0; (void)fa1;
-}
-__device__ __forceinline__ void sqrt_ieee2(double x0, double x1, double &o0, double &o1)
-{
-    const bool c0 = x0 < 0x1p-767, c1 = x1 < 0x1p-767;           // tiny arguments are scaled by 2^256 ...
-    x0 = __builtin_amdgcn_ldexp(x0, c0 ? 256 : 0); x1 = __builtin_amdgcn_ldexp(x1, c1 ? 256 : 0);
-    const double y0 = __builtin_amdgcn_rsq(x0), y1 = __builtin_amdgcn_rsq(x1);
-    double g0 = x0 * y0, g1 = x1 * y1, h0 = y0 * 0.5, h1 = y1 * 0.5;
-    const double r0 = fma(-h0, g0, 0.5), r1 = fma(-h1, g1, 0.5);
-    g0 = fma(g0, r0, g0); g1 = fma(g1, r1, g1);
-    h0 = fma(h0, r0, h0); h1 = fma(h1, r1, h1);
-    double d0 = fma(-g0, g0, x0), d1 = fma(-g1, g1, x1);
-    g0 = fma(d0, h0, g0); g1 = fma(d1, h1, g1);
-    d0 = fma(-g0, g0, x0); d1 = fma(-g1, g1, x1);
-    g0 = fma(d0, h0, g0); g1 = fma(d1, h1, g1);
-    g0 = __builtin_amdgcn_ldexp(g0, c0 ? -128 : 0); g1 = __builtin_amdgcn_ldexp(g1, c1 ? -128 : 0);   // ... and the root by 2^-128
-    o0 = __builtin_amdgcn_class(x0, 0x260) ? x0 : g0;            // +-0 and +inf pass through
-    o1 = __builtin_amdgcn_class(x1, 0x260) ? x1 : g1;
-}
-// omega and cg_rr of two rays (same expressions, same order as dispersion())
-__device__ __forceinline__ void dispersion_pair(const double (&kk)[2], const double (&ll)[2], const double (&mm)[2],
-                                                const double (&f2)[2], double bvf2, double (&cgr)[2])
-{
-    const double kh20 = kk[0] * kk[0] + ll[0] * ll[0], kh21 = kk[1] * kk[1] + ll[1] * ll[1];
-    const double m20 = mm[0] * mm[0], m21 = mm[1] * mm[1];
-    const double vk20 = kh20 + m20, vk21 = kh21 + m21;
-    double a0, a1, om0, om1, b0, b1;
-    div_ieee2(bvf2 * kh20 + f2[0] * m20, vk20, bvf2 * kh21 + f2[1] * m21, vk21, a0, a1);
-    sqrt_ieee2(a0, a1, om0, om1);
-    div_ieee2(-mm[0] * (om0 * om0 - f2[0]), om0, -mm[1] * (om1 * om1 - f2[1]), om1, b0, b1);
-    div_ieee2(b0, vk20, b1, vk21, cgr[0], cgr[1]);
 }
 
 // saturation cap :601 (rho_f already interpolated)
