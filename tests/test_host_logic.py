@@ -194,3 +194,20 @@ def test_committed_counter_table_matches_the_kernel_sources():
         assert os.path.exists(os.path.join(os.path.dirname(bench.__file__), e["source"]))
         assert e.get("valu_wave_insts_per_ray_step", 0) > 0
         assert ("bytes_per_ray_step" in e) != ("bytes_per_ray_launch" in e)
+
+
+def test_checkpoint_reader_checks_the_format_before_touching_the_gpu(tmp_path):
+    """`Propagator.load_checkpoint` reads a plain .npz (no pickle) and refuses another format version before it creates a
+    context -- checkable without a GPU."""
+    from msgwam_amd import _capi
+    bad = str(tmp_path / "bad.npz")
+    with open(bad, "wb") as f:
+        np.savez(f, format=np.array(_capi.Propagator.CHECKPOINT_FORMAT + 1), dens=np.zeros(3), ngrid=np.array(101),
+                 float32_state=np.array(False))
+    with pytest.raises(_capi.MsgwError, match="checkpoint format"):
+        _capi.Propagator.load_checkpoint(bad)
+    pickled = str(tmp_path / "obj.npz")
+    with open(pickled, "wb") as f:
+        np.savez(f, format=np.array([{"a": 1}], dtype=object))
+    with pytest.raises(ValueError, match="allow_pickle|pickled|Object arrays"):
+        _capi.Propagator.load_checkpoint(pickled)
