@@ -94,8 +94,6 @@ __global__ void __launch_bounds__(BLOCK, 2) k_ray_stage_chain(const ChainArgsT<T
     const long long start = (long long)blockIdx.x * a.rays_per_block;
     const long long end = min(a.n, start + a.rays_per_block);
     int wmin = INT_MAX, wmax = INT_MIN;
-    DepWindow acc;
-    acc.clear();
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = start + (long long)t * (BLOCK * RPT);
         if (base >= end) break;
@@ -315,9 +313,8 @@ __global__ void __launch_bounds__(BLOCK, 2) k_ray_stage_chain(const ChainArgsT<T
             }
         }
         deposit_tile<2, T, RPT>(lo, up, nlo, nup, vol, pay, s_gs, a.dzs, a.inv_dzs, a.mk_ok, s_rows + wave * 2 * ncp,
-                                ncp, lane, wmin, wmax, acc);
+                                ncp, lane, wmin, wmax);
     }
-    flush_window(acc, s_rows + wave * 2 * ncp, ncp, lane);
     // the workgroups' rows are reduced inside the launch (ticketed, fixed order: the per-stage kernel's protocol) to the
     // one row the column kernel reads -- or, for the single-RHS probe, left as sparse rows for k_flux_reduce1
     if (STAGE != 3 && h.group_reduce) flush_rows_group<2, T>(s_rows, ncp, s_rng, lds, tid, a);

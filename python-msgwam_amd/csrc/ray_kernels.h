@@ -199,30 +199,34 @@ __device__ __forceinline__ void wave_sum2(double a, double b, double &ta, double
     ta = readlane_f64(v, 0);
     tb = readlane_f64(v, 32);
 }
-// The same two sums, left IN the wave: every lane of 0-31 holds sum(a), every lane of 32-63 holds sum(b).
-__device__ __forceinline__ double wave_sum2_halves(double a, double b)
+// The deposit's sums over a wavefront (NP = 2): only the first four steps of that butterfly -- every group of 8 lanes then
+// holds its own sum of a (lanes 0-31) or b (lanes 32-63) -- and ONE lane per group adds it to the wave's private LDS row
+// with ds_add_f64 (4 lane-operations per component and level).  The ray kernels are bound by VALU issue (DESIGN.md 4 K1f,
+// 6): the remaining two butterfly steps and the bookkeeping of the lane-distributed level window (cmp, two selects, add)
+// were 10 of 22 VALU instructions per level; the LDS atomics issue on the LDS port.  Measured at config 3 with 0 / 1 / 2 /
+// 3 DPP steps before the atomic (32 / 16 / 8 / 4 lane-operations per component): 34.4 / 31.1 / 30.5-30.8 / 30.4-30.5 us
+// per step against 31.6 for the full butterfly.  The row belongs to ONE wave and a wave's LDS operations are performed in
+// program order, lanes in lane order: the sums are reproducible bit for bit from run to run (the repeated-run tests hold).
+__device__ __forceinline__ void group_sum2_to_lds(double a, double b, double *row_c, int ncp, int lane)
 {
     const u32x2_t lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const u32x2_t hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
     double v = __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
-    v = v + dpp_f64<0xB1>(v);
-    v = v + dpp_f64<0x4E>(v);
-    v = v + dpp_f64<0x141>(v);
-    v = v + dpp_f64<0x140>(v);
-    const u32x2_t rlo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
-    const u32x2_t rhi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
-    return __hiloint2double((int)rhi.x, (int)rlo.x) + __hiloint2double((int)rhi.y, (int)rlo.y);
+    v = v + dpp_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v = v + dpp_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v = v + dpp_f64<0x141>(v);    // row_half_mirror: every lane of a group of 8 holds the group's sum
+    if ((lane & 7) == 0)
+        __hip_atomic_fetch_add(row_c + (lane >> 5) * ncp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ float wave_sum2_halves(float a, float b)
+__device__ __forceinline__ void group_sum2_to_lds(float a, float b, double *row_c, int ncp, int lane)
 {
     const u32x2_t s = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     float v = __uint_as_float(s.x) + __uint_as_float(s.y);
     v = v + dpp_f32<0xB1>(v);
     v = v + dpp_f32<0x4E>(v);
     v = v + dpp_f32<0x141>(v);
-    v = v + dpp_f32<0x140>(v);
-    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
+    if ((lane & 7) == 0)
+        __hip_atomic_fetch_add(row_c + (lane >> 5) * ncp, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // float32 form of the same butterfly: one dword per value, and the DPP steps fold into v_add_f32_dpp
 // (about 10 instructions for both sums).  Same fixed order.
@@ -388,41 +392,22 @@ __device__ __forceinline__ void deposit_indices(T lo, T up, bool valid, T dz, T 
     if (ood || !valid) { nlo = 0; nup = 0; }                 // :135, :153-154
 }
 
-// Per-level sums of a wave.  NP = 2 (the pseudo-momentum fluxes of the RHS): the 64-lane butterfly leaves sum(a) in
-// every lane of 0-31 and sum(b) in every lane of 32-63 (wave_sum2_halves), and ONE float64 register per lane keeps the
-// wave's sums of a WINDOW of 32 levels: lane L owns level base + (L & 31) of payload L >> 5, so adding a level's sums
-// is a compare, a select and an add (round 1: lane-0 read-outs, a broadcast and a select chain over absolute-level
-// registers -- 28 instructions per level, as many as the butterfly).  The window is wave-uniform and moves with the
-// rays (flush_window folds it into the wave's private LDS row: 64 distinct addresses, no conflict); a pass of
-// neighbouring tiles practically never leaves it, and columns of any height take the same path.
+// Per-level sums of a wave.  NP = 2 (the pseudo-momentum fluxes of the RHS): group_sum2_to_lds -- four butterfly steps, then
+// one lane of every group of 8 adds the group's sum to the wave's private LDS row (ds_add_f64).  (Rounds 1-3 ran the
+// whole 64-lane butterfly and kept the sums of a window of 32 levels in one register per lane, folded into the row when
+// the window moved: 22 VALU instructions per level against 12.)  Columns of any height take the same path.
 // NP = 1 (diagnostic projections): plain butterfly, lane 0 adds to the LDS row.
-// T = float: weights, payloads and the butterfly are float32; the window register and the rows are float64.
-struct DepWindow {
-    int base;                     // wave-uniform first level of the window; -1: empty
-    double v;                     // lane L: sum of level base + (L & 31), payload L >> 5
-    __device__ __forceinline__ void clear() { base = -1; v = 0.0; }
-};
-constexpr int DEP_WIN = 32;
+// T = float: weights, payloads and the butterfly steps are float32; the rows are float64.
 #ifdef MSGW_DBG_LEVELS
 __device__ unsigned long long g_dbg_levels, g_dbg_tiles, g_dbg_wide;
 #endif
-
-__device__ __forceinline__ void flush_window(DepWindow &W, double *row, int ncp, int lane)
-{
-    if (W.base >= 0) {                                       // wave-uniform
-        const int c = W.base + (lane & 31);
-        if (c < ncp) row[(lane >> 5) * ncp + c] += W.v;
-    }
-    W.clear();
-}
 
 template <int NP, typename T, int RPT = Real<T>::RPT>
 __device__ __forceinline__ void deposit_tile(const T (&lo)[RPT], const T (&up)[RPT],
                                              const int (&nlo)[RPT], const int (&nup)[RPT],
                                              const T (&vol)[RPT], const T (&pay)[NP][RPT],
                                              const T *sG, T dz, T cdz, int ok,
-                                             double *row, int ncp, int lane, int &wmin, int &wmax,
-                                             DepWindow &W)
+                                             double *row, int ncp, int lane, int &wmin, int &wmax)
 {
     int mylo = INT_MAX, myhi = INT_MIN;
 #pragma unroll
@@ -445,11 +430,7 @@ __device__ __forceinline__ void deposit_tile(const T (&lo)[RPT], const T (&up)[R
     return;
 #endif
     if (whi - wlo <= SPAN_MAX) {
-        if (NP == 2) {
-            if (W.base >= 0 && (wlo < W.base || whi > W.base + DEP_WIN)) flush_window(W, row, ncp, lane);
-            if (W.base < 0) W.base = max(wlo - (DEP_WIN - SPAN_MAX) / 2, 0);    // room to drift both ways
-        }
-        const int mylevel = lane & 31;
+
         for (int c = wlo; c < whi; ++c) {                    // uniform trip count: all lanes stay
             const T g0 = sG[c], g1 = sG[c + 1];              // LDS broadcast reads
             T s[NP];
@@ -466,8 +447,7 @@ __device__ __forceinline__ void deposit_tile(const T (&lo)[RPT], const T (&up)[R
                 }
             }
             if (NP == 2) {
-                const double t = (double)wave_sum2_halves(s[0], s[NP - 1]);
-                W.v = W.v + ((mylevel == c - W.base) ? t : 0.0);
+                group_sum2_to_lds(s[0], s[NP - 1], row + c, ncp, lane);
             } else {
                 const double t = (double)wave_sum(s[0]);
                 if (lane == 0) row[c] += t;
@@ -770,8 +750,6 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
     // with resident tiles the kernel is FP64-VALU bound, not HBM bound: streamed tiles then carry cg_rr of
     // their state through memory (8 B store + 8 B load per ray-stage) instead of re-evaluating it
     constexpr bool CGMEM = NRES > 0 && NRES <= CGMEM_MAX_NRES && LAG && DEPOSIT && !SAT;
-    DepWindow acc;                                           // the wave's level sums of this pass
-    acc.clear();
     // The exact constant division (div_const) has a run-time fall-back for grid spacings whose significand is all ones;
     // the resident-tile flavours of the persistent kernel are only launched when it is not needed (plan_persist), so
     // that the test and its branches leave their level loop (twice per ray, once per ray and level).
@@ -812,7 +790,6 @@ __device__ __forceinline__ void process_tiles(const StageArgsT<T> a, const Stage
         MSGW_STAMP_AT(3 + 2 * (t & 1));
         if (more) load_tile<T, STAGE, SAT, FVEC, DEPOSIT, DIRECT, CGMEM>(cur, a, base + TILE, tid, end);
     }
-    if (DEPOSIT) flush_window(acc, s_rows + wave * 2 * ncp, ncp, lane);
 }
 
 // Deposit-only pass over this workgroup's rays (no stores): wave_projection(var=0) of the CURRENT
@@ -825,8 +802,6 @@ __device__ __forceinline__ void deposit_pass(const StageArgsT<T> a, const StageL
     constexpr int TILE = Real<T>::TILE;
     const int nc = a.ng - 1, ncp = a.ng - 2;
     int wmin = INT_MAX, wmax = INT_MIN;
-    DepWindow acc;
-    acc.clear();
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = start + (long long)t * TILE;
         if (base >= end) break;
@@ -855,9 +830,8 @@ __device__ __forceinline__ void deposit_pass(const StageArgsT<T> a, const StageL
         }
         if (CGSTORE && valid[0] && base >= cg_from) storev(a.r.cg(), off, cg2);   // streamed tiles of the persistent kernel
         deposit_tile<2, T>(lo, up, nlo, nup, vol, pay, L.gs, a.dzs, a.inv_dzs, a.mk_ok,
-                           L.rows + wave * 2 * ncp, ncp, lane, wmin, wmax, acc);
+                           L.rows + wave * 2 * ncp, ncp, lane, wmin, wmax);
     }
-    flush_window(acc, L.rows + wave * 2 * ncp, ncp, lane);
 }
 
 // stage the static tables of the column (float64 in global memory) into the LDS views
@@ -1170,8 +1144,6 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
     for (int i = tid; i < WAVES * NP * ncp; i += BLOCK) s_rows[i] = 0.0;
     __syncthreads();
     int wmin = INT_MAX, wmax = INT_MIN;
-    DepWindow win;
-    win.clear();
     const long long tile0 = (long long)blockIdx.x * a.tiles_per_block;
     for (int t = 0; t < a.tiles_per_block; ++t) {
         const long long base = (tile0 + t) * (long long)TILE;
@@ -1258,9 +1230,8 @@ __global__ void __launch_bounds__(BLOCK) k_project(const ProjArgsT<T> a)
             else pay[0][r] = (a.var == 1) ? cgr * dens[r] : dens[r];                     // :167, :184
         }
         deposit_tile<NP, T>(lo, up, nlo, nup, vol, pay, s_G, a.dz, a.cdz, a.mk_ok,
-                            s_rows + wave * NP * ncp, ncp, lane, wmin, wmax, win);
+                            s_rows + wave * NP * ncp, ncp, lane, wmin, wmax);
     }
-    if (NP == 2) flush_window(win, s_rows + wave * NP * ncp, ncp, lane);
     flush_rows<NP>(s_rows, ncp, s_rng, wave, lane, tid, wmin, wmax, a.partial, a.ranges);
 }
 
