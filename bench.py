@@ -578,8 +578,8 @@ def main():
                             "achieved_is": "ALGORITHMIC bytes (SURVEY 8d) of one launch / its HIP-event duration; every ray "
                                            "streams through HBM once per RK stage on this path", **common}
             roofline["limiter"] = {
-                "config3": "VALU issue inside the tiles (a pass of a ray workgroup: table 1.8 + tiles 7.2 + publish 1.2 us; the two "
-                           "workgroups of a CU do the first and the last at the same time) and the reduce chain, 9.6 us from the "
+                "config3": "VALU issue inside the tiles (a pass of a ray workgroup: table 1.8 + tiles 6.8 + publish 1.2 us; the two "
+                           "workgroups of a CU do the first and the last at the same time) and the reduce chain, 9.4 us from the "
                            "last row to the release, which is as long as a pass (DESIGN.md 6, 8; profiles/r03_persist_timeline.txt)",
                 "config4": "as config3, plus the rank sum on the reduce chain (DESIGN.md 5a)",
                 "config5": "VALU issue (online saturation is a second table look-up and two more divisions per ray-stage); the "
