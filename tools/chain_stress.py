@@ -55,7 +55,10 @@ while time.time() < t_end:
         p.step(60.0, k, flags)
     got = chain_state(p, st, hprop, nz)
     p.close()
-    tol = 1e-4 if f32 else 5e-9                     # (float64: one ray in 1e8 amplifies the device sin / cos ulps to 1e-9)
+    # float64: one ray in 1e8 amplifies the device sin / cos ulps to 1e-9; the tall column (rays up to 155 km, where the
+    # density is 1e-9 of the ground's) amplifies summation-order noise by orders of magnitude per step (tests/test_gpu_parity.py,
+    # _tall_case): 1.8e-8 seen after five steps
+    tol = 1e-4 if f32 else (1e-6 if tall else 5e-9)
     for i, k in enumerate(STATE_KEYS[:9]):
         w = np.asarray(want[i], dtype=np.float64)
         fin = np.isfinite(w)
