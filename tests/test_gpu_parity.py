@@ -234,6 +234,30 @@ def test_bitwise_reproducible_and_graph_equals_eager(monkeypatch):
         assert np.array_equal(a, c, equal_nan=True), f"graph replay differs from eager in {k}"
 
 
+@pytest.mark.parametrize("dtype,n,sorted_z", [("f64", 1_000_000, True), ("f32", 1_250_000, True), ("f64", 300_001, False)])
+def test_persistent_kernel_is_reproducible_bit_for_bit(dtype, n, sorted_z):
+    """The deposit finishes its cross-lane sums with LDS atomics on a wave-private row (csrc/ray_kernels.h,
+    group_sum2_to_lds); unsorted rays take per-lane LDS atomics.  Both must give the same bits every time: three runs of the
+    default persistent flavour at the bench sizes (and of an unsorted case) are compared bit for bit."""
+    s, st = _random_case(n, 77, dtype == "f32", "uniform", sorted_z)
+    st[0] = st[0] * 1e-3
+    outs = []
+    for _ in range(3):
+        p = _capi.Propagator(len(s.grid), n, dtype=dtype)
+        dens, lam, phi, rr, drr, kk, ll, mm, dmm, uu, vv = st
+        p.set_config(s.bvf, s.phi0, s.kappa, s.saturate_online)
+        p.set_column(s.grid, s.grids, s.rhobar, s.pressure_gradient, uu, vv)
+        p.upload_rays(dens, rr, drr, kk, ll, mm, dmm, phi, s.dkk, s.dll, s.rr_mm_area)
+        p.step(60.0, 3)
+        p.step(60.0, 4)
+        assert p.counters()["persist_steps"] == 4
+        outs.append(list(p.download_rays()) + list(p.download_column()))
+        p.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_result_independent_of_workgroup_geometry():
     """Different blocks-per-CU change the reduction tree; results stay within reduction noise."""
     s, st = _random_case(150_000, 32, False, "uniform", True)
